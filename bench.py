@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the MI355X truck-trailer hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one vector step over all envs of the rank.  Workloads:
+  ddpg  (default, BASELINE.json config 3): actor forward + OU noise for N envs -> env step kernel
+        -> transitions into the device replay ring -> one DDPG learn() (batch 256) per vector step;
+  env   (config 2): random policy (Philox) -> env step kernel, auto-reset.
+Inputs are synthetic (reference reset distribution, random-init 400x300 networks) and resident in
+HBM before the timed region.  One JSON line on rank 0; see DESIGN.md "Measurement" for the fields."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B_ALG = 313            # algorithmic bytes per env-step
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--n-envs", type=int, default=65536, help="envs PER GPU (weak scaling)")
+    ap.add_argument("--workload", choices=("ddpg", "env"), default="ddpg")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--replay-slots", type=int, default=64, help="ring length in vector steps (capacity = slots*N)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-graph", action="store_true", help="run learn() eagerly instead of as a hipGraph")
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds):
+    """Oracle timed on the host cores (rank 0, N=1 only): the structure-faithful Python/scipy twin of the
+    reference's step loop on ONE core (the reference is single-threaded), random policy, reset on done.
+    The plain-C port on all cores is reported next to it as the optimised-CPU line."""
+    import numpy as np
+    from oracle import c_oracle
+    from oracle.simv2_twin import Simv2Twin
+    env = Simv2Twin()
+    rng = np.random.RandomState(0)
+    env.reset(seed=0)
+    for _ in range(200):  # warm-up
+        if env.step(np.array([rng.uniform(-1, 1) * np.pi / 4], np.float32))[2]:
+            env.reset()
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(500):
+            if env.step(np.array([rng.uniform(-1, 1) * np.pi / 4], np.float32))[2]:
+                env.reset()
+        n += 500
+    dt = time.perf_counter() - t0
+    cores = len(os.sched_getaffinity(0))
+    c_oracle.rollout_random(256, 50, seed=1, nthreads=cores)
+    t1 = time.perf_counter()
+    cn, _ = c_oracle.rollout_random(4096, 400, seed=2, nthreads=cores)
+    cdt = time.perf_counter() - t1
+    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} steps of oracle/simv2_twin.py (numpy + scipy solve_ivp RK45 + reward object per step), "
+                      f"uniform-random steering, reset on done, {dt:.1f} s",
+            "c_port": {"value": cn / cdt, "unit": "env-steps/s", "cores": cores,
+                       "sample": f"{cn} steps of oracle/tt_oracle.c (fixed DP5, OpenMP), {cdt:.2f} s"}}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path is a HIP kernel)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+
+    n = args.n_envs
+    env = TruckTrailerVecEnv(n, device=dev)
+    env.reset(seed=27 + rank)
+
+    ev_pairs = []
+
+    def timed_env_step(action, **kw):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()            # env kernel is launched on torch's current stream (vec_env._stream)
+        out = env.step(action, auto_reset=True, **kw)
+        e1.record()
+        ev_pairs.append((e0, e1))
+        return out
+
+    if args.workload == "env":
+        act = torch.empty(n, dtype=torch.float32, device=dev)
+        counter = [0]
+
+        def one_step(timed):
+            env.random_actions(123 + rank, counter[0], out=act)
+            counter[0] += 1
+            (timed_env_step if timed else lambda a: env.step(a, auto_reset=True))(act)
+        workload = f"simv2 N={n}/GPU, random policy U(-1,1)*pi/4, auto-reset (BASELINE config 2 at bench size)"
+        extra = {}
+    else:
+        from ddpg_trucktrailer_amd.rollout import DDPGRollout
+        loop = DDPGRollout(env, batch_size=args.batch, replay_slots=args.replay_slots, seed=27 + rank,
+                           world_size=world, use_graph=not args.no_graph)
+
+        def one_step(timed):
+            loop.step(timed_env_step if timed else None)
+        workload = (f"simv2 N={n}/GPU + full DDPG learn() per vector step (actor/critic 400x300, batch {args.batch}, "
+                    f"OU noise, replay ring {args.replay_slots}xN) (BASELINE config 3)")
+        extra = {"batch": args.batch, "replay_capacity": args.replay_slots * n}
+
+    for _ in range(args.warmup):
+        one_step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
+    total_env_steps = n * world * args.steps
+    value = total_env_steps / elapsed
+    achieved = (B_ALG * n) / (kern_ms * 1e-3) / 1e9
+    out = {
+        "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": dict({"workload": workload, "n_envs_per_gpu": n, "n_envs_total": n * world}, **extra),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_step",
+                     "kernel_ms": kern_ms, "alg_bytes_per_env_step": B_ALG,
+                     "kernel_env_steps_per_s": n / (kern_ms * 1e-3)},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,85 @@
+"""ctypes binding of libttenv.so (include/ttenv.h).  The product has no CPU fallback: if the
+library is missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libttenv.so")
+
+OBS_DIM = 23
+TT_OK, TT_EINVAL, TT_ENOMEM, TT_EHIP, TT_ENODEV = 0, -1, -2, -3, -4
+F_JACKKNIFE, F_OUT_OF_MAP, F_MAX_STEPS, F_GOAL_REACHED, F_GOAL_PASSED, F_EXCESSIVE_BACK, F_SUCCESS = (1 << i for i in range(7))
+VIOLATIONS = ("none", "jackknife", "jackknife_warning", "major_boundary", "minor_boundary", "past_the_goal",
+              "max_step", "excessive_backward")
+INFO_ROWS = ("total_reward", "progress_reward", "heading_reward", "orientation_reward", "staged_success",
+             "safety_penalty", "exploration_bonus", "final_success_bonus", "backward_penalty", "smoothness_penalty",
+             "cumulative_backward", "movement_budget")
+NINFO = len(INFO_ROWS)
+
+
+class TTParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("L1", "L2", "hitch_offset", "v1x", "dt", "map_min_x", "map_max_x", "map_min_y",
+                                          "map_max_y", "max_steer", "position_threshold", "orientation_threshold",
+                                          "step_length")] + \
+               [("extra_steps", C.c_int32), ("fixed_max_steps", C.c_int32), ("term_mask", C.c_uint32),
+                ("variant", C.c_int32), ("goal", C.c_double * 3), ("reset_lo", C.c_double * 3),
+                ("reset_hi", C.c_double * 3)]
+
+
+class TTInfo(C.Structure):
+    _fields_ = [("comp", C.c_void_p), ("violation", C.c_void_p), ("flags", C.c_void_p)]
+
+
+class TTError(RuntimeError):
+    pass
+
+
+_P, _I, _U64 = C.c_void_p, C.c_int, C.c_uint64
+_SIGNATURES = {
+    "tt_version": (C.c_int, []),
+    "tt_last_error": (C.c_char_p, [_P]),
+    "tt_params_default": (C.c_int, [_I, C.POINTER(TTParams)]),
+    "tt_env_create": (C.c_int, [_I, _I, C.POINTER(TTParams), C.POINTER(_P)]),
+    "tt_env_destroy": (C.c_int, [_P]),
+    "tt_env_num_envs": (C.c_int, [_P]),
+    "tt_env_reset": (C.c_int, [_P, _P, _U64, _P, _P]),
+    "tt_env_set_pose": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _P]),
+    "tt_env_set_attrs": (C.c_int, [_P, _P, _I, _P, _P, _P, _P]),
+    "tt_env_set_state": (C.c_int, [_P, _P, _I, _P, _P]),
+    "tt_env_get_state": (C.c_int, [_P, _P, _P]),
+    "tt_env_set_max_steps": (C.c_int, [_P, _P, _I, _P, _P]),
+    "tt_env_get_episode": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "tt_env_observe": (C.c_int, [_P, _P, _P, _P]),
+    "tt_env_step": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(TTInfo), _I, _P]),
+    "tt_random_actions": (C.c_int, [_I, _U64, _U64, _P, _P]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """dlopen libttenv.so and declare every entry point of include/ttenv.h."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc, handle=None):
+    if rc != TT_OK:
+        msg = load().tt_last_error(handle)
+        raise TTError(f"libttenv error {rc}: {msg.decode() if msg else '?'}")
+
+
+def default_params(variant=0):
+    p = TTParams()
+    check(load().tt_params_default(variant, C.byref(p)))
+    return p

@@ -1,0 +1,41 @@
+"""Build libttenv.so (HIP, gfx950) in-tree with hipcc.  No JIT cache: the .so sits next to this
+file so that it travels to the GPU box with the repo snapshot."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = [os.path.join(HERE, "csrc", "ttenv.hip")]
+HDR = [os.path.join(ROOT, "include", "ttenv.h")]
+LIB = os.path.join(HERE, "libttenv.so")
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in SRC + HDR)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into ddpg-trucktrailer_amd/libttenv.so."""
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + os.path.join(ROOT, "include"), "-o", LIB] + SRC
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

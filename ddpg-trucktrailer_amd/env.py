@@ -1,0 +1,198 @@
+"""Gym-style single-env façade over libttenv.so: the reference's `Truck_trailer_Env_2` surface
+(truck_trailer_sim/simv2.py:20-101, 459-545) so that a trainv2-shaped loop
+(DDPG/trainv2.py:488-531) and the pose-override pattern of its other callers
+(DDPG/test.py:96-115, heatmap.py:79-168) run unchanged, with the step itself executed by the
+HIP kernel.  Host code here only mirrors attributes and moves 23 floats per call.
+
+Same names, argument meaning and return types as the reference: reset(seed) -> (obs f32[23], {});
+step(action) -> (obs, reward np.float64, done bool, info dict) (old 4-tuple gym API)."""
+import math
+import random
+
+import numpy as np
+import torch
+
+from ddpg_trucktrailer_amd import _lib as L
+from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (shape / low / high / dtype / sample)."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.shape = tuple(shape)
+        self.dtype = np.dtype(dtype)
+        self.low = np.full(self.shape, low, dtype=dtype)
+        self.high = np.full(self.shape, high, dtype=dtype)
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+
+_SYNCED = ("startx", "starty", "startyaw", "goalx", "goaly", "goalyaw", "L2")
+
+
+class Truck_trailer_Env_2:
+    metadata = {'render.modes': ['human', 'rgb_array']}
+    reward_range = (-float("inf"), float("inf"))
+    _variant = 0
+
+    def __init__(self, device=None):
+        p = L.default_params(self._variant)
+        # env 0 is the env; env 1 is scratch for compute_observation(state, steering) on arbitrary states
+        self._vec = TruckTrailerVecEnv(2, device=device, params=p)
+        object.__setattr__(self, "_dirty", set())
+        self.min_map_x, self.max_map_x = p.map_min_x, p.map_max_x
+        self.min_map_y, self.max_map_y = p.map_min_y, p.map_max_y
+        self.L1, self.hitch_offset, self.v1x, self.dt, self.time = p.L1, p.hitch_offset, p.v1x, p.dt, 0
+        self.min_steering_angle, self.max_steering_angle = -p.max_steer, p.max_steer
+        self.workspace_width = self.max_map_x - self.min_map_x
+        self.workspace_height = self.max_map_y - self.min_map_y
+        self.max_expected_distance = np.sqrt(self.workspace_width ** 2 + self.workspace_height ** 2)
+        self.observation_dim = L.OBS_DIM
+        self.observation_space = Box(-1.0, 1.0, (self.observation_dim,), np.float32)
+        self.action_space = Box(self.min_steering_angle, self.max_steering_angle, (1,), np.float32)
+        self.position_threshold = p.position_threshold
+        self.orientation_threshold = p.orientation_threshold
+        self.steering_angle = 0
+        self.episode_steps = 0
+        self.reward_state = None
+        self.jackknife = self.out_of_map = self.max_steps_reached = self.goal_reached = self.goal_passed = False
+        self.excessive_backward = False
+        object.__setattr__(self, "L2", p.L2)
+        object.__setattr__(self, "goalx", p.goal[0])
+        object.__setattr__(self, "goaly", p.goal[1])
+        object.__setattr__(self, "goalyaw", p.goal[2])
+        object.__setattr__(self, "startx", p.goal[0])
+        object.__setattr__(self, "starty", p.goal[1] + 30.0)
+        object.__setattr__(self, "startyaw", math.pi / 2)
+        object.__setattr__(self, "max_episode_steps", 110)
+        object.__setattr__(self, "_state", np.zeros(6, np.float64))
+        self._state_pending = False
+        self._state_stale = True
+
+    # attribute writes are mirrored to the device lazily, before the next kernel that reads them
+    def __setattr__(self, name, value):
+        if name in _SYNCED:
+            self._dirty.add("attrs")
+        elif name == "max_episode_steps":
+            self._dirty.add("max_steps")
+        object.__setattr__(self, name, value)
+
+    @property
+    def state(self):
+        if self._state_stale and not self._state_pending:
+            object.__setattr__(self, "_state", self._vec.state[0].cpu().numpy())
+            self._state_stale = False
+        return self._state
+
+    @state.setter
+    def state(self, value):
+        object.__setattr__(self, "_state", np.asarray(value, dtype=np.float64).reshape(6).copy())
+        self._state_pending = True
+        self._state_stale = False
+
+    def _sync(self, idx=(0,)):
+        d = self._dirty
+        if "attrs" in d:
+            self._vec.set_attrs(start=[[self.startx, self.starty, self.startyaw]],
+                                goal=[[self.goalx, self.goaly, self.goalyaw]], L2=[self.L2], idx=list(idx))
+        if "max_steps" in d:
+            self._vec.set_max_steps([int(self.max_episode_steps)], idx=list(idx))
+        d.clear()
+        if self._state_pending:
+            self._vec.set_state(self._state[None, :], idx=list(idx))
+            self._state_pending = False
+
+    # ------------------------------------------------------------------ reference API
+    def compute_max_steps(self):
+        """simv2.py:263-267 (host arithmetic on the mirrored attributes)."""
+        if self._vec.params.fixed_max_steps > 0:
+            return int(self._vec.params.fixed_max_steps)
+        d0 = np.sqrt((self.goalx - self.startx) ** 2 + (self.goaly - self.starty) ** 2)
+        return int(d0 / self._vec.params.step_length) + int(self._vec.params.extra_steps)
+
+    def compute_observation(self, state, steering_angle):
+        """simv2.py:103-181 for an arbitrary state, on the scratch env (GPU)."""
+        v = self._vec
+        v.set_attrs(goal=[[self.goalx, self.goaly, self.goalyaw]], idx=[1])
+        v.set_state(np.asarray(state, dtype=np.float64).reshape(1, 6), idx=[1])
+        steer = torch.tensor([0.0, float(np.asarray(steering_angle).reshape(-1)[0])], dtype=torch.float32)
+        if self._state_pending or self._dirty:
+            self._sync()
+        obs = v.observe(steering=steer)
+        return obs[1].cpu().numpy()
+
+    compute_observation1 = compute_observation
+
+    def generate_valid_random_poses(self):
+        """simv2.py:328-339: numpy's legacy global stream, draw order x, y, yaw."""
+        p = self._vec.params
+        sx = np.random.uniform(p.reset_lo[0], p.reset_hi[0])
+        sy = np.random.uniform(p.reset_lo[1], p.reset_hi[1])
+        syaw = np.random.uniform(p.reset_lo[2], p.reset_hi[2])
+        return (sx, sy, syaw, p.goal[0], p.goal[1], p.goal[2])
+
+    def reset(self, seed=None, options=None):
+        if seed is not None:
+            np.random.seed(seed)
+            random.seed(seed)
+        sx, sy, syaw, gx, gy, gyaw = self.generate_valid_random_poses()
+        for k, val in zip(_SYNCED[:6], (sx, sy, syaw, gx, gy, gyaw)):
+            object.__setattr__(self, k, val)
+        obs = self._vec.set_pose([[sx, sy, syaw]], goal=[[gx, gy, gyaw]], L2=[self.L2], idx=[0])
+        object.__setattr__(self, "max_episode_steps", self.compute_max_steps())
+        self._dirty.clear()
+        self._state_pending = False
+        self._state_stale = True
+        self.episode_steps = 0
+        self.reward_state = None
+        return obs[0].cpu().numpy(), {}
+
+    def step(self, action):
+        if isinstance(action, np.ndarray):
+            action = action.reshape(-1)[0]
+        self._sync()
+        a32 = np.float32(action)
+        self.steering_angle = float(np.clip(np.float64(a32), self.min_steering_angle, self.max_steering_angle))
+        act = torch.tensor([a32, 0.0], dtype=torch.float32)
+        obs, _rew, done, inf = self._vec.step(act, auto_reset=False, info=True)
+        comp = inf["comp"][:, 0].cpu().numpy()
+        flags = int(inf["flags"][0].item())
+        viol = int(inf["violation"][0].item())
+        self.episode_steps += 1
+        self._state_stale = True
+        self.jackknife = bool(flags & L.F_JACKKNIFE)
+        self.out_of_map = bool(flags & L.F_OUT_OF_MAP)
+        self.max_steps_reached = bool(flags & L.F_MAX_STEPS)
+        self.goal_reached = bool(flags & L.F_GOAL_REACHED)
+        self.goal_passed = bool(flags & L.F_GOAL_PASSED)
+        self.excessive_backward = bool(flags & L.F_EXCESSIVE_BACK)
+        c = dict(zip(L.INFO_ROWS, (np.float64(x) for x in comp)))
+        budget = c["movement_budget"]
+        info = {
+            'total_reward': c["total_reward"], 'distance_reward': np.float64(0.0),
+            'progress_reward': c["progress_reward"], 'heading_reward': c["heading_reward"],
+            'orientation_reward': c["orientation_reward"], 'staged_success': c["staged_success"],
+            'safety_penalty': c["safety_penalty"], 'exploration_bonus': c["exploration_bonus"],
+            'final_success_bonus': c["final_success_bonus"], 'violation_type': L.VIOLATIONS[viol],
+            'backward_penalty': c["backward_penalty"], 'smoothness_penalty': c["smoothness_penalty"],
+            'backward_movement_info': {'cumulative_backward': c["cumulative_backward"], 'movement_budget': budget,
+                                       'excess_movement': max(0.0, c["cumulative_backward"] - budget),
+                                       'penalty': c["backward_penalty"]},
+            'success': bool(flags & L.F_SUCCESS),
+        }
+        self.reward_state = True  # the carry lives on the device; non-None marks "episode started"
+        return obs[0].cpu().numpy(), c["total_reward"], bool(done[0].item()), info
+
+    def render(self, mode='human'):
+        raise NotImplementedError("rendering (simv2.py:547-605) is out of scope of the MI355X hot path")
+
+    def close(self):
+        self._vec.close()
+
+
+class Truck_trailer_Env_1(Truck_trailer_Env_2):
+    """simv1 constants (truck_trailer_sim/simv1.py:23-99): L1 5.74, L2 10.192, 300-step cap,
+    termination = jackknife | out of map | max steps | goal."""
+    _variant = 1

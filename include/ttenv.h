@@ -1,0 +1,149 @@
+/* ttenv.h -- C ABI of libttenv.so: the batched truck-trailer backing environment on MI355X.
+ *
+ * The reference (pain7576/ddpg-trucktrailer) has no FFI; the interface its callers use for
+ * this path is the gym-style Python surface of `Truck_trailer_Env_2`
+ * (truck_trailer_sim/simv2.py:20-101, 459-545) plus the public attributes they read and
+ * write (DDPG/trainv2.py:488-531, DDPG/test.py:96-115, DDPG/heatmap.py:79-168).  Each entry
+ * point below names the reference interface it replaces; INTEGRATION.md shows the ctypes
+ * stub that binds them behind that Python surface.
+ *
+ * Conventions
+ *  - plain C: opaque handle, plain pointers and sizes, no C++/torch types;
+ *  - every call returns 0 (TT_OK) or a negative TT_E* code and never throws;
+ *    tt_last_error() returns a message owned by the handle (or by the library for a NULL handle);
+ *  - every array pointer is a DEVICE pointer owned by the caller (e.g. torch `data_ptr()`),
+ *    layouts as stated per argument; N = number of envs of the handle;
+ *  - work is enqueued on the caller's stream (`tt_stream_t` is `hipStream_t`; NULL = the
+ *    default stream) and is asynchronous; nothing here synchronises or allocates after create;
+ *  - one host thread per handle; handles are independent (one process per GPU, one handle per
+ *    process is the multi-GPU model).
+ */
+#ifndef TTENV_H
+#define TTENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TT_VERSION 1
+#define TT_OBS_DIM 23 /* simv2.py:76 */
+
+enum { TT_OK = 0, TT_EINVAL = -1, TT_ENOMEM = -2, TT_EHIP = -3, TT_ENODEV = -4 };
+
+/* termination causes, one bit each, in the order of simv2.py:528-541; bit 6 = reward-side success */
+enum {
+    TT_F_JACKKNIFE = 1, TT_F_OUT_OF_MAP = 2, TT_F_MAX_STEPS = 4, TT_F_GOAL_REACHED = 8,
+    TT_F_GOAL_PASSED = 16, TT_F_EXCESSIVE_BACK = 32, TT_F_SUCCESS = 64
+};
+#define TT_TERM_SIMV2 0x3F /* all six causes end an episode (simv2.py:541) */
+#define TT_TERM_SIMV1 0x0F /* jackknife | out of map | max steps | goal (simv1.py:432) */
+
+/* `violation_type` of reward_functionv1.py:378-419, last writer wins */
+enum {
+    TT_V_NONE = 0, TT_V_JACKKNIFE, TT_V_JACKKNIFE_WARNING, TT_V_MAJOR_BOUNDARY, TT_V_MINOR_BOUNDARY,
+    TT_V_PAST_THE_GOAL, TT_V_MAX_STEP, TT_V_EXCESSIVE_BACKWARD
+};
+
+/* rows of tt_info.comp, the reward_info dict of reward_functionv1.py:489-504 */
+enum {
+    TT_I_TOTAL = 0, TT_I_PROGRESS, TT_I_HEADING, TT_I_ORIENT, TT_I_STAGED, TT_I_SAFETY, TT_I_EXPLORE,
+    TT_I_FINAL, TT_I_BACKWARD, TT_I_SMOOTH, TT_I_CUMBACK, TT_I_BUDGET, TT_NINFO
+};
+
+typedef struct ihipStream_t *tt_stream_t; /* == hipStream_t */
+typedef struct tt_env tt_env;
+
+/* Constants of Truck_trailer_Env_2.__init__ (simv2.py:23-101); variant 1 = simv1.py:23-99. */
+typedef struct tt_params {
+    double L1, L2;             /* wheelbase, trailer length (L2 is the default; per-env via tt_env_set_pose) */
+    double hitch_offset, v1x;  /* 0.0, -5.012 */
+    double dt;                 /* 0.08: one fixed Dormand-Prince step per env step */
+    double map_min_x, map_max_x, map_min_y, map_max_y; /* -40..40 */
+    double max_steer;          /* np.radians(45) */
+    double position_threshold, orientation_threshold; /* 0.5, deg2rad(15) */
+    double step_length;        /* 0.40096 (simv2.py:265) */
+    int32_t extra_steps;       /* 75 */
+    int32_t fixed_max_steps;   /* 0 = int(d0/step_length)+extra_steps (simv2); 300 (simv1.py:95) */
+    uint32_t term_mask;        /* which TT_F_* bits end an episode */
+    int32_t variant;           /* 0 simv2, 1 simv1 */
+    double goal[3];            /* default goal x, y, yaw: 0, -30, pi/2 (simv2.py:335-337) */
+    double reset_lo[3], reset_hi[3]; /* start x, y, yaw ~ U(lo, hi) (simv2.py:331-333) */
+} tt_params;
+
+/* Optional per-step detail: the `info` dict of env.step (reward_functionv1.py:489-504) and the
+ * public flags callers read afterwards (heatmap.py:159-168).  Any member may be NULL. */
+typedef struct tt_info {
+    double *comp;       /* [TT_NINFO, N] f64, row-major by component (row TT_I_TOTAL = f64 reward) */
+    uint8_t *violation; /* [N] TT_V_* */
+    uint8_t *flags;     /* [N] TT_F_* bits, before masking with term_mask */
+} tt_info;
+
+int tt_version(void);
+const char *tt_last_error(const tt_env *env);
+
+/* Truck_trailer_Env_2() / Truck_trailer_Env_1(): fills `out` with the reference constants. */
+int tt_params_default(int variant, tt_params *out);
+
+/* Truck_trailer_Env_2.__init__ for N envs on HIP device `device` (simv2.py:23-101). */
+int tt_env_create(int n_envs, int device, const tt_params *params, tt_env **out);
+int tt_env_destroy(tt_env *env);
+int tt_env_num_envs(const tt_env *env);
+
+/* env.reset(seed) (simv2.py:459-498) for the envs whose mask byte is non-zero (NULL = all):
+ * start pose ~ reset_lo/hi from a counter-based Philox stream keyed by `seed` (distributional
+ * parity with np.random.seed; the bit-exact seeded pose is tt_env_set_pose's job), state stored
+ * f32-rounded, step counter and reward carry cleared, obs rows written with steering 0.
+ * Also fixes the seed used by tt_env_step's auto-reset.  obs_out [N,23] f32 may be NULL. */
+int tt_env_reset(tt_env *env, const uint8_t *mask, uint64_t seed, float *obs_out, tt_stream_t stream);
+
+/* The callers' pose-override pattern (DDPG/test.py:96-115, heatmap.py:79-122): for j < k set
+ * env idx[j] (idx NULL = env j) to start[j] = (startx, starty, startyaw), optional goal[j] and
+ * L2[j], state = trailer pose with the truck L2 ahead rounded to f32, max_episode_steps =
+ * compute_max_steps(), episode cleared; writes obs rows idx[j] of obs_out [N,23] if non-NULL. */
+int tt_env_set_pose(tt_env *env, const int32_t *idx, int k, const double *start /*[k,3]*/,
+                    const double *goal /*[k,3] or NULL*/, const double *L2 /*[k] or NULL*/, float *obs_out,
+                    tt_stream_t stream);
+
+/* Plain attribute writes `env.startx/starty/startyaw = ...`, `env.goalx/goaly/goalyaw = ...`,
+ * `env.L2 = ...` (heatmap.py:79-89): like tt_env_set_pose's arguments (each may be NULL = keep)
+ * but WITHOUT touching the kinematic state, the step counter or the reward carry. */
+int tt_env_set_attrs(tt_env *env, const int32_t *idx, int k, const double *start /*[k,3] or NULL*/,
+                     const double *goal /*[k,3] or NULL*/, const double *L2 /*[k] or NULL*/, tt_stream_t stream);
+
+/* `env.state = ...` / `env.state` (simv2.py:489, trainv2.py:499,522): raw f64 kinematic state
+ * psi1, psi2, x1, y1, x2, y2.  set: state [k,6] row-major for envs idx[j]; get: [6,N] SoA. */
+int tt_env_set_state(tt_env *env, const int32_t *idx, int k, const double *state, tt_stream_t stream);
+int tt_env_get_state(tt_env *env, double *state_out, tt_stream_t stream);
+
+/* `env.max_episode_steps = ...` (heatmap.py:96) for envs idx[j]. */
+int tt_env_set_max_steps(tt_env *env, const int32_t *idx, int k, const int32_t *max_steps, tt_stream_t stream);
+
+/* Episode bookkeeping read-back; any pointer may be NULL.  steps/max_steps [N] i32;
+ * start, goal [3,N] f64 (startx.., goalx..: trainv2.py:503-508); L2 [N] f64. */
+int tt_env_get_episode(tt_env *env, int32_t *steps, int32_t *max_steps, double *start, double *goal, double *L2,
+                       tt_stream_t stream);
+
+/* env.compute_observation(env.state, steering) (simv2.py:103-181) for all envs;
+ * steering [N] f32 radians or NULL for 0.  obs_out [N,23] f32 row-major. */
+int tt_env_observe(tt_env *env, const float *steering, float *obs_out, tt_stream_t stream);
+
+/* env.step(action) for all N envs (simv2.py:499-545): clip to +-max_steer, one DP5 step of the
+ * kinematic ODE in f64, 23-dim observation, reward_functionv1 reward with its carry, flags.
+ *   action [N] f32 radians; obs [N,23] f32 row-major; reward [N] f32; done [N] u8;
+ *   info optional (NULL or members NULL).
+ * auto_reset != 0: an env that is done is re-placed like tt_env_reset (its obs row is then the
+ * fresh episode's first observation; reward/done/info still describe the finished step).  The
+ * reference never resets by itself (trainv2.py:489); auto_reset = 0 reproduces that. */
+int tt_env_step(tt_env *env, const float *action, float *obs, float *reward, uint8_t *done, const tt_info *info,
+                int auto_reset, tt_stream_t stream);
+
+/* "random policy" of BASELINE.json config 2: out[i] = U(-1,1) * pi/4 from Philox(seed, step). */
+int tt_random_actions(int n, uint64_t seed, uint64_t step, float *out, tt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTENV_H */
