@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true", help="run learn() eagerly instead of as a hipGraph")
+    ap.add_argument("--graph-steps", type=int, default=50, help="env workload: vector steps per captured hipGraph")
     return ap.parse_args()
 
 
@@ -94,46 +95,56 @@ def main():
     env = TruckTrailerVecEnv(n, device=dev)
     env.reset(seed=27 + rank)
 
-    ev_pairs = []
-
-    def timed_env_step(action, **kw):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()            # env kernel is launched on torch's current stream (vec_env._stream)
-        out = env.step(action, auto_reset=True, **kw)
-        e1.record()
-        ev_pairs.append((e0, e1))
-        return out
-
+    graph_k = 1
     if args.workload == "env":
-        act = torch.empty(n, dtype=torch.float32, device=dev)
-        counter = [0]
+        # one vector step = one launch of the fused kernel (action drawn in-kernel).  Launch-bound in eager
+        # Python at this N, so G steps are captured into one hipGraph and a "step" replays 1/G of it.
+        graph_k = max(1, min(args.graph_steps, args.steps))
+        while args.steps % graph_k or args.warmup % graph_k:
+            graph_k -= 1
+        graph = None
+        if graph_k > 1:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                env.step_random(123 + rank, auto_reset=True)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(graph_k):
+                    env.step_random(123 + rank, auto_reset=True)
 
         def one_step(timed):
-            env.random_actions(123 + rank, counter[0], out=act)
-            counter[0] += 1
-            (timed_env_step if timed else lambda a: env.step(a, auto_reset=True))(act)
-        workload = f"simv2 N={n}/GPU, random policy U(-1,1)*pi/4, auto-reset (BASELINE config 2 at bench size)"
-        extra = {}
+            if graph is not None:
+                graph.replay()
+            else:
+                env.step_random(123 + rank, auto_reset=True)
+        workload = (f"simv2 N={n}/GPU, random policy U(-1,1)*pi/4 drawn in-kernel, auto-reset "
+                    f"(BASELINE config 2 at bench size), hipGraph of {graph_k} steps")
+        extra = {"graph_steps": graph_k}
     else:
         from ddpg_trucktrailer_amd.rollout import DDPGRollout
         loop = DDPGRollout(env, batch_size=args.batch, replay_slots=args.replay_slots, seed=27 + rank,
                            world_size=world, use_graph=not args.no_graph)
 
         def one_step(timed):
-            loop.step(timed_env_step if timed else None)
+            loop.step()
         workload = (f"simv2 N={n}/GPU + full DDPG learn() per vector step (actor/critic 400x300, batch {args.batch}, "
                     f"OU noise, replay ring {args.replay_slots}xN) (BASELINE config 3)")
         extra = {"batch": args.batch, "replay_capacity": args.replay_slots * n}
 
-    for _ in range(args.warmup):
-        one_step(False)
+    def run(k_steps, timed):
+        for _ in range(k_steps // graph_k):
+            one_step(timed)
+
+    run(args.warmup, False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if graph_k == 1:
+        env.profile(args.steps)      # per-dispatch HIP events on the step kernel, inside the timed region
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(True)
+    run(args.steps, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -143,8 +154,15 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
+    if graph_k > 1:
+        # a captured launch cannot carry its own events: time the same kernel on the same state right after,
+        # eagerly, with the per-dispatch events (the timed region above is untouched by this)
+        env.profile(min(args.steps, 2000))
+        for _ in range(min(args.steps, 2000)):
+            env.step_random(123 + rank, auto_reset=True)
+    kern_total_ms, kern_launches = env.profile_read()
+    env.profile(0)
+    kern_ms = kern_total_ms / max(1, kern_launches)
     total_env_steps = n * world * args.steps
     value = total_env_steps / elapsed
     achieved = (B_ALG * n) / (kern_ms * 1e-3) / 1e9

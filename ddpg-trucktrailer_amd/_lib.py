@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libttenv.so")
+LIB_PATH = os.environ.get("TT_LIB_PATH") or os.path.join(HERE, "libttenv.so")  # override: kernel-variant A/B runs
 
 OBS_DIM = 23
 TT_OK, TT_EINVAL, TT_ENOMEM, TT_EHIP, TT_ENODEV = 0, -1, -2, -3, -4
@@ -51,6 +51,10 @@ _SIGNATURES = {
     "tt_env_get_episode": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "tt_env_observe": (C.c_int, [_P, _P, _P, _P]),
     "tt_env_step": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(TTInfo), _I, _P]),
+    "tt_env_step_random": (C.c_int, [_P, _U64, _P, _P, _P, _P, C.POINTER(TTInfo), _I, _P]),
+    "tt_env_rollout_random": (C.c_int, [_P, _I, _U64, _P, _P, _P, _P]),
+    "tt_env_profile": (C.c_int, [_P, _I]),
+    "tt_env_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "tt_random_actions": (C.c_int, [_I, _U64, _U64, _P, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)

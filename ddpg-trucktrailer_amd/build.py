@@ -25,16 +25,18 @@ def stale():
     return any(os.path.getmtime(p) > t for p in SRC + HDR)
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into ddpg-trucktrailer_amd/libttenv.so."""
-    if not force and not stale():
+def build(force=False, verbose=False, defines=(), out=None):
+    """Compile every HIP source for gfx950 into ddpg-trucktrailer_amd/libttenv.so.
+    `defines`/`out` build a kernel variant next to it (A/B timing via TT_LIB_PATH)."""
+    if out is None and not force and not stale():
         return LIB
+    out = out or LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(ROOT, "include"), "-o", LIB] + SRC
+           "-I" + os.path.join(ROOT, "include"), "-o", out] + ["-D" + d for d in defines] + SRC
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

@@ -177,6 +177,38 @@ class TruckTrailerVecEnv:
                                          C.byref(ti) if ti is not None else None, 1 if auto_reset else 0, self._stream()))
         return obs, rew, done, inf
 
+    def step_random(self, policy_seed=123, auto_reset=True, info=False, action_out=None, obs_out=None, reward_out=None,
+                    done_out=None):
+        """step() with the random policy of BASELINE.json config 2 drawn inside the kernel (graph-capturable)."""
+        obs = self.obs if obs_out is None else obs_out
+        rew = self.reward if reward_out is None else reward_out
+        done = self.done if done_out is None else done_out
+        inf, ti = None, None
+        if info:
+            comp, viol, flags, ti = self._info()
+            inf = dict(comp=comp, violation=viol, flags=flags)
+        self._check(self.lib.tt_env_step_random(self._h, int(policy_seed) & (2 ** 64 - 1), _ptr(action_out), _ptr(obs),
+                                                _ptr(rew), _ptr(done), C.byref(ti) if ti is not None else None,
+                                                1 if auto_reset else 0, self._stream()))
+        return obs, rew, done, inf
+
+    def rollout_random(self, k_steps, policy_seed=123, obs_out=None, reward_sum=None, episodes_done=None):
+        """k_steps random-policy steps in one launch (state stays in registers); returns the last obs buffer."""
+        obs = self.obs if obs_out is None else obs_out
+        self._check(self.lib.tt_env_rollout_random(self._h, int(k_steps), int(policy_seed) & (2 ** 64 - 1), _ptr(obs),
+                                                   _ptr(reward_sum), _ptr(episodes_done), self._stream()))
+        return obs
+
+    def profile(self, max_launches):
+        """Time the next `max_launches` step-kernel dispatches with per-dispatch HIP events (0 = off)."""
+        self._check(self.lib.tt_env_profile(self._h, int(max_launches)))
+
+    def profile_read(self):
+        """-> (sum of step-kernel durations in ms, number of launches timed)."""
+        ms, cnt = C.c_double(), C.c_int64()
+        self._check(self.lib.tt_env_profile_read(self._h, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
     def random_actions(self, seed, step, out=None):
         out = torch.empty(self.n_envs, dtype=torch.float32, device=self.device) if out is None else out
         L.check(self.lib.tt_random_actions(self.n_envs, int(seed), int(step), _ptr(out), self._stream()))

@@ -93,8 +93,9 @@ int tt_env_destroy(tt_env *env);
 int tt_env_num_envs(const tt_env *env);
 
 /* env.reset(seed) (simv2.py:459-498) for the envs whose mask byte is non-zero (NULL = all):
- * start pose ~ reset_lo/hi from a counter-based Philox stream keyed by `seed` (distributional
- * parity with np.random.seed; the bit-exact seeded pose is tt_env_set_pose's job), state stored
+ * start pose ~ reset_lo/hi from counter-based Philox keyed by (seed, env, episode number) (distributional
+ * parity with np.random.seed; the bit-exact seeded pose is tt_env_set_pose's job).  A full reset (mask NULL)
+ * restarts every env at episode 0, so the poses are a pure function of `seed`; state stored
  * f32-rounded, step counter and reward carry cleared, obs rows written with steering 0.
  * Also fixes the seed used by tt_env_step's auto-reset.  obs_out [N,23] f32 may be NULL. */
 int tt_env_reset(tt_env *env, const uint8_t *mask, uint64_t seed, float *obs_out, tt_stream_t stream);
@@ -140,7 +141,27 @@ int tt_env_observe(tt_env *env, const float *steering, float *obs_out, tt_stream
 int tt_env_step(tt_env *env, const float *action, float *obs, float *reward, uint8_t *done, const tt_info *info,
                 int auto_reset, tt_stream_t stream);
 
-/* "random policy" of BASELINE.json config 2: out[i] = U(-1,1) * pi/4 from Philox(seed, step). */
+/* tt_env_step with BASELINE.json config 2's "random policy" drawn inside the kernel:
+ * action = U(-1,1) * pi/4 from Philox keyed by (policy_seed, env, step-in-episode, episode number), so no
+ * host-side counter changes between launches and a captured hipGraph of K steps replays correctly.
+ * action_out [N] f32 (the drawn steering, e.g. for a replay buffer) may be NULL. */
+int tt_env_step_random(tt_env *env, uint64_t policy_seed, float *action_out, float *obs, float *reward,
+                       uint8_t *done, const tt_info *info, int auto_reset, tt_stream_t stream);
+
+/* K vector steps of the random policy in ONE launch (SURVEY.md §8d iii): each env stays in registers for
+ * k_steps steps with in-kernel auto-reset; only the last observation is stored.  obs_out [N,23], reward_sum [N]
+ * f32 (sum of the k_steps rewards) and episodes_done [N] i32 may each be NULL. */
+int tt_env_rollout_random(tt_env *env, int k_steps, uint64_t policy_seed, float *obs_out, float *reward_sum,
+                          int32_t *episodes_done, tt_stream_t stream);
+
+/* Measurement hook (no reference counterpart): time each of the next `max_launches` step-kernel dispatches
+ * with a HIP event pair bound to the dispatch itself (hipExtLaunchKernelGGL), on the stream they are launched
+ * on; max_launches = 0 switches it off.  tt_env_profile_read waits for the recorded launches, adds them to the
+ * running totals and returns sum of kernel durations [ms] and their count.  Not capturable into a hipGraph. */
+int tt_env_profile(tt_env *env, int max_launches);
+int tt_env_profile_read(tt_env *env, double *total_ms, int64_t *launches);
+
+/* "random policy" of BASELINE.json config 2 as a stand-alone action generator: out[i] = U(-1,1) * pi/4 from Philox(seed, step). */
 int tt_random_actions(int n, uint64_t seed, uint64_t step, float *out, tt_stream_t stream);
 
 #ifdef __cplusplus
