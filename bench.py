@@ -26,8 +26,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n-envs", type=int, default=65536, help="envs PER GPU (weak scaling)")
     ap.add_argument("--workload", choices=("ddpg", "env"), default="ddpg")
     ap.add_argument("--batch", type=int, default=256)

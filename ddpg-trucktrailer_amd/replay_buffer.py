@@ -1,0 +1,92 @@
+"""Replay memory.
+
+ReplayBuffer mirrors DDPG/replay_buffer.py:3-34 (store_transition / sample_buffer, uniform sampling WITH
+replacement through numpy's global RNG) with the storage on the device in float32 instead of float64 host
+arrays.  TrajectoryRing is the vector form used by the N-env loop: the env kernel writes straight into it."""
+import numpy as np
+import torch
+
+
+class ReplayBuffer:
+    def __init__(self, max_size, input_shape, n_actions, device=None):
+        self.mem_size = int(max_size)
+        self.mem_cntr = 0
+        self.device = torch.device(device) if device is not None else torch.device('cpu')
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.state_memory = torch.zeros((self.mem_size, *input_shape), **f32)
+        self.new_state_memory = torch.zeros((self.mem_size, *input_shape), **f32)
+        self.action_memory = torch.zeros((self.mem_size, n_actions), **f32)
+        self.reward_memory = torch.zeros(self.mem_size, **f32)
+        self.terminal_memory = torch.zeros(self.mem_size, dtype=torch.bool, device=self.device)
+
+    def store_transition(self, state, action, reward, state_, done):
+        index = self.mem_cntr % self.mem_size
+        self.state_memory[index] = torch.as_tensor(np.asarray(state), dtype=torch.float32)
+        self.action_memory[index] = torch.as_tensor(np.asarray(action), dtype=torch.float32)
+        self.reward_memory[index] = float(reward)
+        self.new_state_memory[index] = torch.as_tensor(np.asarray(state_), dtype=torch.float32)
+        self.terminal_memory[index] = bool(done)
+        self.mem_cntr += 1
+
+    def store_batch(self, states, actions, rewards, states_, dones):
+        """Bulk insert (expert transitions, trainv2.py:457-466): k transitions at once, wrapping around."""
+        k = len(rewards)
+        idx = (torch.arange(k, device=self.device) + self.mem_cntr) % self.mem_size
+        self.state_memory[idx] = torch.as_tensor(states, dtype=torch.float32, device=self.device)
+        self.action_memory[idx] = torch.as_tensor(actions, dtype=torch.float32, device=self.device).reshape(k, -1)
+        self.reward_memory[idx] = torch.as_tensor(rewards, dtype=torch.float32, device=self.device)
+        self.new_state_memory[idx] = torch.as_tensor(states_, dtype=torch.float32, device=self.device)
+        self.terminal_memory[idx] = torch.as_tensor(dones, dtype=torch.bool, device=self.device)
+        self.mem_cntr += k
+
+    def sample_buffer(self, batch_size):
+        max_mem = min(self.mem_cntr, self.mem_size)
+        batch = torch.as_tensor(np.random.choice(max_mem, batch_size), device=self.device)
+        return (self.state_memory[batch], self.action_memory[batch], self.reward_memory[batch],
+                self.new_state_memory[batch], self.terminal_memory[batch])
+
+
+class TrajectoryRing:
+    """Time-major ring of the last T vector steps of N envs, all on the device, f32.
+
+    obs[t] is the observation the policy saw at vector step t and obs[t+1] the one the env returned, so a
+    transition (t, n) is (obs[t][n], act[t][n], rew[t][n], obs[t+1][n], done[t][n]) and each observation is
+    stored ONCE (101 B per transition instead of 193 B).  For a finished env obs[t+1][n] is the first
+    observation of its next episode; DDPG zeroes Q' for done transitions (DDPG_agent.py:89), so that row is
+    never used.  The env kernel writes obs[t+1], rew[t], done[t] in place: inserting costs no copy."""
+
+    def __init__(self, n_envs, slots, obs_dim, device):
+        assert slots >= 3
+        self.n, self.slots, self.device = n_envs, slots, device
+        self.obs = torch.zeros((slots, n_envs, obs_dim), dtype=torch.float32, device=device)
+        self.act = torch.zeros((slots, n_envs), dtype=torch.float32, device=device)
+        self.rew = torch.zeros((slots, n_envs), dtype=torch.float32, device=device)
+        self.done = torch.zeros((slots, n_envs), dtype=torch.uint8, device=device)
+        self.k = 0                                                          # vector steps completed (host)
+        self.k_dev = torch.zeros((), dtype=torch.int64, device=device)      # same, on the device (graph-safe)
+
+    @property
+    def capacity(self):
+        return (self.slots - 1) * self.n
+
+    def __len__(self):
+        return min(self.k, self.slots - 1) * self.n
+
+    def slot(self, k=None):
+        return (self.k if k is None else k) % self.slots
+
+    def advance(self):
+        self.k += 1
+        self.k_dev += 1
+
+    def sample(self, batch_size, generator=None):
+        """Uniform with replacement over the stored transitions; index math on the device (k_dev), so the call
+        can sit inside a captured hipGraph."""
+        dev = self.device
+        u = torch.rand((2, batch_size), device=dev, generator=generator)
+        avail = torch.clamp(self.k_dev, max=self.slots - 1)                          # complete transitions, in steps
+        back = (u[0] * avail).long().clamp_(max=self.slots - 2)                      # 0 = newest
+        t = torch.remainder(self.k_dev - 1 - back, self.slots)
+        n = (u[1] * self.n).long().clamp_(max=self.n - 1)
+        t1 = torch.remainder(t + 1, self.slots)
+        return (self.obs[t, n], self.act[t, n].unsqueeze(1), self.rew[t, n], self.obs[t1, n], self.done[t, n].bool())

@@ -1,0 +1,88 @@
+"""The N-env DDPG loop: the vector form of the reference's training loop (DDPG/trainv2.py:511-531).
+
+Per vector step, for all N envs of this rank at once:
+    mu = actor(obs);  a = mu + OU noise            (DDPG_agent.choose_action, trainv2.py:512)
+    scaled = clip(a, -1, 1) * f32(pi/4)            (trainv2.py:516)
+    obs', r, done = env.step(scaled)               (HIP kernel; finished envs restart in-kernel)
+    remember(obs, a, r, obs', done)                (a = the UNCLIPPED noisy action, trainv2.py:525):
+                                                   obs', r, done are written by the kernel straight into the ring
+    learn()                                        (one gradient step, batch from the ring)
+Everything stays on the device; learn() is captured into a hipGraph (sampling included)."""
+import math
+
+import numpy as np
+import torch
+
+from ddpg_trucktrailer_amd.agent import Agent
+from ddpg_trucktrailer_amd.noise import VecOUNoise
+from ddpg_trucktrailer_amd.replay_buffer import TrajectoryRing
+
+
+class DDPGRollout:
+    def __init__(self, env, batch_size=256, replay_slots=64, seed=27, alpha=1e-4, beta=1e-3, tau=1e-3, gamma=0.99,
+                 fc1_dims=400, fc2_dims=300, world_size=1, use_graph=True, agent=None):
+        self.env, self.n, self.device = env, env.n_envs, env.device
+        self.batch_size = batch_size
+        torch.manual_seed(seed)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed)
+        self.agent = agent if agent is not None else Agent(
+            alpha=alpha, beta=beta, input_dims=(env.observation_dim,), tau=tau, n_actions=1, gamma=gamma,
+            fc1_dims=fc1_dims, fc2_dims=fc2_dims, batch_size=batch_size, device=self.device,
+            capturable=use_graph, replay=False)
+        if world_size > 1:
+            self.agent.enable_data_parallel()
+        self.ring = TrajectoryRing(self.n, replay_slots, env.observation_dim, self.device)
+        self.noise = VecOUNoise(self.n, self.device)
+        self.high = float(np.float32(math.pi / 4))       # env.action_space.high (f32 pi/4, simv2.py:86-91)
+        self.scaled = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+        # the first observation of every env goes into slot 0
+        env.observe(out=self.ring.obs[0])
+        self.use_graph = use_graph and world_size == 1 and self.device.type == "cuda"
+        self.graph = None
+        self.vector_steps = 0
+
+    # -------------------------------------------------------------- acting
+    @torch.no_grad()
+    def act(self, obs, act_out):
+        mu = self.agent.actor(obs).view(-1)
+        torch.add(mu, self.noise.sample(), out=act_out)                   # stored action: unclipped mu + noise
+        torch.clamp(act_out, -1.0, 1.0, out=self.scaled).mul_(self.high)  # what the env is driven with
+        return self.scaled
+
+    # -------------------------------------------------------------- learning
+    def _learn_once(self):
+        s, a, r, s2, d = self.ring.sample(self.batch_size)
+        self.agent.learn_batch(s, a, r, s2, d)
+
+    def learn(self):
+        if self.ring.k < 2:
+            return
+        if not self.use_graph:
+            return self._learn_once()
+        if self.graph is None:
+            # warm up (allocator, Adam state, autograd's AccumulateGrad nodes) on the SAME side stream the
+            # capture then uses: a backward captured on another stream than the one those nodes were created
+            # on needs cross-stream syncs that break the capture
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self._learn_once()
+            side.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side):
+                self._learn_once()
+            torch.cuda.current_stream().wait_stream(side)
+        self.graph.replay()
+
+    # -------------------------------------------------------------- one vector step
+    def step(self):
+        ring = self.ring
+        t, t1 = ring.slot(), ring.slot(ring.k + 1)
+        scaled = self.act(ring.obs[t], ring.act[t])
+        self.env.step(scaled, auto_reset=True, obs_out=ring.obs[t1], reward_out=ring.rew[t], done_out=ring.done[t])
+        self.noise.reset(ring.done[t])
+        ring.advance()
+        self.learn()
+        self.vector_steps += 1

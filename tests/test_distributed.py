@@ -1,0 +1,70 @@
+"""Data-parallel learn(): world_size-2 gloo processes on CPU (the N>1 path of bench.py uses the same code with
+the RCCL backend).  Each rank holds HALF of fixture F5's batch; after the two gradient all-reduces the
+weights must (a) be identical on both ranks and (b) equal the reference's single-process learn() on the whole
+batch (mean of the two half-batch mean-gradients == the full-batch mean-gradient)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, ROOT
+
+F5 = os.path.join(GOLDEN, "f5_learner.npz")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from test_learner import _agent, _load_init
+    z = np.load(F5, allow_pickle=False)
+    torch.manual_seed(100 + rank)                 # different random init per rank: broadcast must fix that
+    agent = _agent(torch.device("cpu"))
+    if rank == 0:
+        _load_init(agent, z)
+    agent.enable_data_parallel()
+    agent.update_network_parameters(tau=1)
+    half = slice(rank * 128, (rank + 1) * 128)
+    f = lambda k: torch.tensor(z[k][half], dtype=torch.float)
+    batch = (f("batch_states"), f("batch_actions"), f("batch_rewards"), f("batch_states_"),
+             torch.tensor(z["batch_dones"][half]))
+    for _ in range(3):
+        agent.learn_batch(*batch)
+    flat = torch.cat([p.detach().reshape(-1) for net in agent._nets() for p in net.parameters()])
+    torch.save(flat, os.path.join(out_dir, f"rank{rank}.pt"))
+    if rank == 0:
+        torch.save({n: getattr(agent, n).state_dict() for n in ("actor", "critic", "target_actor", "target_critic")},
+                   os.path.join(out_dir, "state.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_matches_reference_full_batch(tmp_path):
+    port = _free_port()
+    mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    a = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    b = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    assert torch.equal(a, b), "ranks diverged"
+    z = np.load(F5, allow_pickle=False)
+    state = torch.load(tmp_path / "state.pt", weights_only=True)
+    stride = int(z["sample_stride"])
+    for name, sd in state.items():
+        for k, v in sd.items():
+            got = v.numpy()
+            if k == "fc2.weight":
+                got = got.reshape(-1)[::stride]
+            ref = z[f"after3/{name}/{k}"]
+            assert np.abs(got - ref).max() <= 4e-5 * max(1e-1, np.abs(ref).max()) + 1e-6, (name, k)

@@ -1,0 +1,115 @@
+"""GPU (-m gpu): the DDPG loop on top of the HIP env -- the reference's single-env trainv2 loop through the
+gym facade (BASELINE.json config 1 plumbing) and the N-env vector loop with the device replay ring and the
+hipGraph-captured learn() (config 3)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_trainv2_shaped_single_env_loop(gpu_device):
+    """DDPG/trainv2.py:488-531 verbatim in shape: reset(seed+i), noise.reset, choose_action, clip*high, step,
+    remember(unclipped action), learn."""
+    import torch
+    from ddpg_trucktrailer_amd.agent import Agent
+    from ddpg_trucktrailer_amd.env import Truck_trailer_Env_2
+    env = Truck_trailer_Env_2()
+    torch.manual_seed(27); np.random.seed(27)
+    agent = Agent(alpha=0.0001, beta=0.001, input_dims=env.observation_space.shape, tau=0.001, batch_size=64,
+                  fc1_dims=400, fc2_dims=300, n_actions=env.action_space.shape[0], max_size=5000)
+    assert env.reward_range[0] == -float("inf")
+    total = 0
+    before = [p.detach().clone() for p in agent.actor.parameters()]
+    for i in range(2):
+        observation, info = env.reset(seed=27 + i)
+        assert observation.shape == (23,) and observation.dtype == np.float32 and info == {}
+        if i == 0:   # seed 27 -> the pose fixture F2 recorded from the reference
+            assert abs(env.startx - -4.011043831979627) < 1e-12 and env.max_episode_steps == 205
+        done, score = False, 0
+        agent.noise.reset()
+        while not done:
+            action = agent.choose_action(observation)
+            scaled_action = np.clip(action, -1, 1) * env.action_space.high
+            observation_, reward, done, info = env.step(scaled_action)
+            agent.remember(observation, action, reward, observation_, done)
+            agent.learn()
+            score += reward
+            observation = observation_
+            total += 1
+        assert np.isfinite(score) and info["violation_type"] in ("jackknife", "minor_boundary", "major_boundary",
+                                                                  "past_the_goal", "max_step", "excessive_backward", "none")
+    assert total >= 64 and agent.memory.mem_cntr == total
+    assert any(not torch.equal(a, b) for a, b in zip(before, agent.actor.parameters())), "learn() never ran"
+    env.close()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_vector_loop_ring_and_learn(gpu_device, use_graph):
+    import torch
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    n = 4096
+    env = TruckTrailerVecEnv(n)
+    env.reset(seed=27)
+    loop = DDPGRollout(env, batch_size=256, replay_slots=8, seed=27, use_graph=use_graph)
+    first_obs = loop.ring.obs[0].clone()
+    assert torch.equal(first_obs, env.observe(out=torch.empty_like(first_obs)))
+    # detach(): a clone that keeps its grad_fn pins the parameter's AccumulateGrad node to THIS stream, and a
+    # backward captured on another stream then forks the capture (HIP's EndCapture crashes on that)
+    w0 = [p.detach().clone() for p in loop.agent.critic.parameters()]
+    t0 = [p.detach().clone() for p in loop.agent.target_actor.parameters()]
+    dones = 0
+    for k in range(20):
+        t, t1 = loop.ring.slot(), loop.ring.slot(loop.ring.k + 1)
+        loop.step()
+        ring = loop.ring
+        a, d = ring.act[t], ring.done[t].bool()
+        # the env was driven with clip(a, -1, 1) * f32(pi/4) and the UNCLIPPED action was stored (trainv2.py:516,525)
+        assert torch.equal(loop.scaled, torch.clamp(a, -1, 1) * np.float32(np.pi / 4))
+        assert (a.abs() > 0).all() and torch.isfinite(ring.rew[t]).all()
+        assert (loop.noise.x[d] == 0).all()                                   # noise restarts with the episode
+        cur = env.observe(steering=loop.scaled, out=torch.empty_like(first_obs))
+        assert torch.equal(cur[~d], ring.obs[t1][~d])                         # s' of running envs = env's observation
+        if d.any():
+            assert torch.equal(env.observe(out=torch.empty_like(first_obs))[d], ring.obs[t1][d])   # fresh episode, steering 0
+        dones += int(d.sum())
+    assert loop.ring.k == 20 and len(loop.ring) == 7 * n
+    torch.cuda.synchronize()
+    assert any(not torch.equal(a, b) for a, b in zip(w0, loop.agent.critic.parameters()))
+    assert any(not torch.equal(a, b) for a, b in zip(t0, loop.agent.target_actor.parameters()))
+    for p in list(loop.agent.actor.parameters()) + list(loop.agent.critic.parameters()):
+        assert torch.isfinite(p).all()
+    assert (loop.graph is not None) == use_graph
+    env.close()
+
+
+def test_graph_learn_equals_eager_learn(gpu_device):
+    """One captured learn() replay == one eager learn() from the same weights, batch and Adam state."""
+    import torch
+    from ddpg_trucktrailer_amd.agent import Agent
+    z = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "f5_learner.npz"), allow_pickle=False)
+    from test_learner import _load_init, _batch
+    agents = []
+    for _ in range(2):
+        a = Agent(alpha=1e-4, beta=1e-3, input_dims=(23,), tau=1e-3, n_actions=1, batch_size=256, device=gpu_device,
+                  capturable=True, replay=False)
+        _load_init(a, z)
+        agents.append(a)
+    batch = _batch(z, gpu_device)
+    eager, graphed = agents
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graphed.learn_batch(*batch)        # warm-up step 1 (eager) on both
+    side.synchronize()
+    eager.learn_batch(*batch)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        graphed.learn_batch(*batch)
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay()                            # capture does not execute: this replay is step 2
+    eager.learn_batch(*batch)
+    torch.cuda.synchronize()
+    for name in ("actor", "critic", "target_actor", "target_critic"):
+        for (k, x), y in zip(getattr(eager, name).state_dict().items(), getattr(graphed, name).state_dict().values()):
+            assert torch.allclose(x, y, rtol=1e-5, atol=1e-7), (name, k)
