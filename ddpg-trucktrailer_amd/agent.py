@@ -57,6 +57,7 @@ class Agent():
         self.target_critic = CriticNetwork(beta, input_dims, fc1_dims, fc2_dims, n_actions=n_actions,
                                            name='target_critic', **kw)
         self.update_network_parameters(tau=1)
+        self._critic_params = list(self.critic.parameters())
         self.grad_sync_actor = self.grad_sync_critic = None
         self.last_critic_loss = self.last_actor_loss = None
 
@@ -110,20 +111,27 @@ class Agent():
         with T.no_grad():
             target_actions = self.target_actor.forward(states_)
             critic_value_ = self.target_critic.forward(states_, target_actions)
-            critic_value_ = T.where(done.view(-1, 1), T.zeros_like(critic_value_), critic_value_).view(-1)
+            critic_value_ = critic_value_.masked_fill(done.view(-1, 1), 0.0).view(-1)      # critic_value_[done] = 0.0
             target = (rewards + self.gamma * critic_value_).view(-1, 1)
         critic_value = self.critic.forward(states, actions)
 
-        self.critic.optimizer.zero_grad(set_to_none=False)
+        self.critic.optimizer.zero_grad(set_to_none=True)
         critic_loss = F.mse_loss(target, critic_value)
         critic_loss.backward()
         if self.grad_sync_critic is not None:
             self.grad_sync_critic()
         self.critic.optimizer.step()
 
-        self.actor.optimizer.zero_grad(set_to_none=False)
+        # The actor step differentiates -Q(s, mu(s)) through the ALREADY UPDATED critic.  The reference lets
+        # that backward also deposit gradients in the critic's parameters and throws them away at the next
+        # zero_grad (DDPG_agent.py:95,100-104); not computing them changes nothing the optimizers see.
+        self.actor.optimizer.zero_grad(set_to_none=True)
+        for p in self._critic_params:
+            p.requires_grad_(False)
         actor_loss = T.mean(-self.critic.forward(states, self.actor.forward(states)))
         actor_loss.backward()
+        for p in self._critic_params:
+            p.requires_grad_(True)
         if self.grad_sync_actor is not None:
             self.grad_sync_actor()
         self.actor.optimizer.step()
@@ -142,5 +150,4 @@ class Agent():
                 if tau == 1:
                     T._foreach_copy_(dst, src)
                 else:
-                    T._foreach_mul_(dst, 1.0 - tau)
-                    T._foreach_add_(dst, src, alpha=tau)
+                    T._foreach_lerp_(dst, src, tau)     # theta' + tau*(theta - theta'): one multi-tensor kernel

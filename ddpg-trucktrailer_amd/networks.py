@@ -70,8 +70,9 @@ class CriticNetwork(_Checkpointed):
         _uniform_(self.action_value, 1. / np.sqrt(self.action_value.weight.data.size()[0]))
         self.device = _pick_device(device)
         self.to(self.device)
-        self.optimizer = optim.Adam(self.parameters(), lr=beta, weight_decay=0.01,
-                                    capturable=capturable and self.device.type == 'cuda')
+        on_gpu = self.device.type == 'cuda'   # fused = one multi-tensor kernel per step; same update rule
+        self.optimizer = optim.Adam(self.parameters(), lr=beta, weight_decay=0.01, capturable=capturable and on_gpu,
+                                    fused=on_gpu)
 
     def forward(self, state, action):
         state_value = F.relu(self.bn1(self.fc1(state)))
@@ -100,7 +101,8 @@ class ActorNetwork(_Checkpointed):
         _uniform_(self.mu, 0.003)
         self.device = _pick_device(device)
         self.to(self.device)
-        self.optimizer = optim.Adam(self.parameters(), lr=alpha, capturable=capturable and self.device.type == 'cuda')
+        on_gpu = self.device.type == 'cuda'
+        self.optimizer = optim.Adam(self.parameters(), lr=alpha, capturable=capturable and on_gpu, fused=on_gpu)
 
     def forward(self, state):
         x = F.relu(self.bn1(self.fc1(state)))
