@@ -22,7 +22,8 @@ class TTParams(C.Structure):
                                           "map_max_y", "max_steer", "position_threshold", "orientation_threshold",
                                           "step_length")] + \
                [("extra_steps", C.c_int32), ("fixed_max_steps", C.c_int32), ("term_mask", C.c_uint32),
-                ("variant", C.c_int32), ("goal", C.c_double * 3), ("reset_lo", C.c_double * 3),
+                ("variant", C.c_int32), ("stateless_reward", C.c_int32), ("reserved_", C.c_int32),
+                ("goal", C.c_double * 3), ("reset_lo", C.c_double * 3),
                 ("reset_hi", C.c_double * 3)]
 
 
@@ -43,6 +44,7 @@ _SIGNATURES = {
     "tt_env_destroy": (C.c_int, [_P]),
     "tt_env_num_envs": (C.c_int, [_P]),
     "tt_env_reset": (C.c_int, [_P, _P, _U64, _P, _P]),
+    "tt_env_set_reset_pool": (C.c_int, [_P, _P, _I]),
     "tt_env_set_pose": (C.c_int, [_P, _P, _I, _P, _P, _P, _P, _P]),
     "tt_env_set_attrs": (C.c_int, [_P, _P, _I, _P, _P, _P, _P]),
     "tt_env_set_state": (C.c_int, [_P, _P, _I, _P, _P]),

@@ -122,6 +122,9 @@ struct KParams {
     int extra_steps, fixed_max;
     unsigned term_mask;
     int npad;  // envs rounded up to a whole tile: row stride of the cold block
+    int stateless;       // simv1.py:435: the reward carries nothing from step to step
+    int pool_m;          // > 0: resets draw from pool[pool_m][3] instead of the box rlo..rhi
+    const double *pool;
 #if TT_TABLE
     KTable t;
 #endif
@@ -395,6 +398,11 @@ __device__ inline void random_pose(const KParams &P, uint64_t seed, uint32_t env
                                    double &syaw) {
     uint32_t r[4];
     philox4x32(env, episode, 0u, 0x7452u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    if (P.pool_m > 0) {  // pre-filtered poses (simv1's Dubins-feasible starts)
+        const double *q = P.pool + 3 * (size_t)(r[3] % (uint32_t)P.pool_m);
+        sx = q[0]; sy = q[1]; syaw = q[2];
+        return;
+    }
     sx = P.rlo[0] + (P.rhi[0] - P.rlo[0]) * u01(r[0]);  // draw order x, y, yaw (simv2.py:331-333)
     sy = P.rlo[1] + (P.rhi[1] - P.rlo[1]) * u01(r[1]);
     syaw = P.rlo[2] + (P.rhi[2] - P.rlo[2]) * u01(r[2]);
@@ -479,7 +487,7 @@ __device__ __forceinline__ void step_env(const KParams &P, Env &e, float action,
     // The reward's three tanh -- dynamic weights (:189-238): tanh(7(jp - 0.3)); progress (:144-187):
     // tanh(prev - cur), tanh((hist[0] - cur)/2) -- are (1 - t)/(1 + t), t = exp(-2|x|).  Two of them, 1/cur
     // and 1/init share ONE division through the product of the denominators.
-    const bool first = pk_steps(pk) == 0u;  // reward_state is None (:40-76)
+    const bool first = pk_steps(pk) == 0u || P.stateless != 0;  // reward_state is None (:40-76)
     const double prev = first ? cur : e.prev, d3 = first ? cur : e.d3, d1 = first ? cur : e.d1;
     const double inst = prev - cur;
     const double net = (d3 - cur) * 0.5;
@@ -561,7 +569,7 @@ __device__ __forceinline__ void step_env(const KParams &P, Env &e, float action,
     const double explore = (double)steps < rmax * 0.5 ? 4.0 : ((double)steps < rmax * 0.8 ? 2.0 : 0.0);
     // backward-movement budget (:240-283)
     e.cum += fmax(0.0, cur - prev);
-    const double budget = 5.0 * fmin(1.0, (double)steps * 0.02);
+    const double budget = 5.0 * fmin(1.0, (double)(P.stateless ? 1u : steps) * 0.02);  // step_count_for_backward_tracking
     const double excess = fmax(0.0, e.cum - budget);
     double back = 0.0;
     if (__any(excess > 0.0)) back = excess > 0.0 ? -(excess * sqrt(excess)) * 0.5 : 0.0;
@@ -901,6 +909,9 @@ KParams make_kparams(const tt_params &p, int npad) {
     k.extra_steps = p.extra_steps; k.fixed_max = p.fixed_max_steps;
     k.term_mask = p.term_mask;
     k.npad = npad;
+    k.stateless = p.stateless_reward;
+    k.pool_m = 0;
+    k.pool = nullptr;
 #if TT_TABLE
     k.t = make_table();
 #endif
@@ -976,6 +987,7 @@ int tt_params_default(int variant, tt_params *out) {
     out->fixed_max_steps = variant ? 300 : 0;
     out->term_mask = variant ? TT_TERM_SIMV1 : TT_TERM_SIMV2;
     out->variant = variant;
+    out->stateless_reward = variant ? 1 : 0;
     out->goal[0] = 0.0; out->goal[1] = -30.0; out->goal[2] = 90.0 * kDeg;
     out->reset_lo[0] = -27.0; out->reset_hi[0] = 27.0;
     out->reset_lo[1] = 0.0; out->reset_hi[1] = 27.0;
@@ -1053,6 +1065,14 @@ int tt_env_reset(tt_env *env, const uint8_t *mask, uint64_t seed, float *obs_out
     hipLaunchKernelGGL(k_reset, dim3(grid_for(env->n)), dim3(BLOCK), 0, stream, env->kp, env->n, env->b, mask, obs_out,
                        env->seed);
     TT_HIP(env, hipGetLastError());
+    return TT_OK;
+}
+
+int tt_env_set_reset_pool(tt_env *env, const double *pool, int m) {
+    if (!env) return fail(nullptr, TT_EINVAL, "tt_env_set_reset_pool: NULL handle");
+    if (m < 0) return fail(env, TT_EINVAL, "tt_env_set_reset_pool: m=%d", m);
+    env->kp.pool_m = pool ? m : 0;
+    env->kp.pool = env->kp.pool_m > 0 ? pool : nullptr;
     return TT_OK;
 }
 

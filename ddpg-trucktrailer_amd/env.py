@@ -193,6 +193,24 @@ class Truck_trailer_Env_2:
 
 
 class Truck_trailer_Env_1(Truck_trailer_Env_2):
-    """simv1 constants (truck_trailer_sim/simv1.py:23-99): L1 5.74, L2 10.192, 300-step cap,
-    termination = jackknife | out of map | max steps | goal."""
+    """simv1 (truck_trailer_sim/simv1.py): L1 5.74, L2 10.192, 300-step cap, termination = jackknife | out of
+    map | max steps | goal, a fresh reward evaluation every step (simv1.py:435), start poses by rejection
+    sampling against the Dubins path to the goal (simv1.py:255-282; seed ignored as in simv1.py:367).
+    Parity unpinned: the reference's simv1 cannot run."""
     _variant = 1
+
+    def generate_valid_random_poses(self, max_attempts=1000):
+        from ddpg_trucktrailer_amd.simv1_reset import generate_valid_random_pose
+        p = self._vec.params
+        goal = (p.goal[0], p.goal[1], p.goal[2])
+        pose = generate_valid_random_pose(random, goal, self.min_map_x, self.max_map_x, max_attempts)
+        if pose is None:
+            raise RuntimeError("no start pose with an in-map Dubins path found")
+        return (*pose, *goal)
+
+    def reset(self, seed=None, options=None):
+        from ddpg_trucktrailer_amd.simv1_reset import plan_dubins_path_backward
+        obs, info = super().reset(seed=None, options=options)
+        self.path_x, self.path_y, self.path_yaw = plan_dubins_path_backward(
+            self.startx, self.starty, self.startyaw, self.goalx, self.goaly, self.goalyaw, curvature=1.0 / 6)
+        return obs, info

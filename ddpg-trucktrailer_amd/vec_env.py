@@ -92,6 +92,15 @@ class TruckTrailerVecEnv:
         self._check(self.lib.tt_env_reset(self._h, _ptr(m), int(seed) & (2 ** 64 - 1), _ptr(obs), self._stream()))
         return obs
 
+    def set_reset_pool(self, poses):
+        """Resets (explicit and in-kernel) draw start poses from this [m,3] pool (x, y, yaw) instead of the box."""
+        if poses is None:
+            self._pool = None
+            self._check(self.lib.tt_env_set_reset_pool(self._h, None, 0))
+            return
+        self._pool = self._as(poses, torch.float64).reshape(-1, 3)      # kept alive here: the library only borrows it
+        self._check(self.lib.tt_env_set_reset_pool(self._h, _ptr(self._pool), self._pool.shape[0]))
+
     def set_pose(self, start, goal=None, L2=None, idx=None, out=None):
         """Pose override: start [k,3] (x, y, yaw), optional goal [k,3], L2 [k], idx [k] (default 0..k-1)."""
         start = self._as(start, torch.float64).reshape(-1, 3)

@@ -69,6 +69,9 @@ typedef struct tt_params {
     int32_t fixed_max_steps;   /* 0 = int(d0/step_length)+extra_steps (simv2); 300 (simv1.py:95) */
     uint32_t term_mask;        /* which TT_F_* bits end an episode */
     int32_t variant;           /* 0 simv2, 1 simv1 */
+    int32_t stateless_reward;  /* 0: the reward carry persists over the episode (simv2.py:347-373);
+                                  1: a fresh RewardFunction every step, nothing carried (simv1.py:435) */
+    int32_t reserved_;
     double goal[3];            /* default goal x, y, yaw: 0, -30, pi/2 (simv2.py:335-337) */
     double reset_lo[3], reset_hi[3]; /* start x, y, yaw ~ U(lo, hi) (simv2.py:331-333) */
 } tt_params;
@@ -99,6 +102,12 @@ int tt_env_num_envs(const tt_env *env);
  * f32-rounded, step counter and reward carry cleared, obs rows written with steering 0.
  * Also fixes the seed used by tt_env_step's auto-reset.  obs_out [N,23] f32 may be NULL. */
 int tt_env_reset(tt_env *env, const uint8_t *mask, uint64_t seed, float *obs_out, tt_stream_t stream);
+
+/* Start-pose pool for resets (simv1.py:255-282 draws poses by rejection sampling against a Dubins-path
+ * feasibility test, which is host logic): when a pool of m >= 1 poses [m,3] f64 (x, y, yaw) is set, tt_env_reset
+ * and the in-kernel auto-reset draw uniformly from it instead of from reset_lo/hi.  The pool stays owned by the
+ * caller and must outlive its use; m = 0 (or pool NULL) goes back to the box distribution. */
+int tt_env_set_reset_pool(tt_env *env, const double *pool, int m);
 
 /* The callers' pose-override pattern (DDPG/test.py:96-115, heatmap.py:79-122): for j < k set
  * env idx[j] (idx NULL = env j) to start[j] = (startx, starty, startyaw), optional goal[j] and

@@ -21,7 +21,8 @@ class Params(C.Structure):
                                           "max_expected_distance", "position_threshold", "orientation_threshold",
                                           "step_length")] + \
                [("extra_steps", C.c_int32), ("fixed_max_steps", C.c_int32), ("term_mask", C.c_uint32),
-                ("variant", C.c_int32), ("goal", C.c_double * 3)]
+                ("variant", C.c_int32), ("stateless_reward", C.c_int32), ("reserved_", C.c_int32),
+                ("goal", C.c_double * 3)]
 
 
 class Env(C.Structure):

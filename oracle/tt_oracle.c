@@ -54,6 +54,7 @@ void tto_params_default(tto_params *p, int variant) {
     p->fixed_max_steps = variant ? 300 : 0;
     p->term_mask = variant ? 0x0F : 0x3F;
     p->variant = variant;
+    p->stateless_reward = variant ? 1 : 0;
     p->goal[0] = 0.0;
     p->goal[1] = -30.0;
     p->goal[2] = 90.0 * DEG;
@@ -157,7 +158,8 @@ static double reward(const tto_params *p, tto_env *e, const float *obs, double *
     const int rmax = (int)(init / p->step_length) + p->extra_steps;
     const float steer_now = atan2f(obs[10], obs[11]);
 
-    if (!e->has_carry) { /* first step of an episode: reward_functionv1.py:40-76 */
+    if (!e->has_carry || p->stateless_reward) { /* first step of an episode: reward_functionv1.py:40-76;
+                                                   simv1.py:435 builds the reward afresh every step */
         e->prev_dist = cur;
         e->prev_steer = steer_now;
         e->cum_back = 0.0;

@@ -28,6 +28,8 @@ typedef struct {
     int32_t fixed_max_steps; /* 0: derive from the start distance (simv2); 300 for simv1 */
     uint32_t term_mask;
     int32_t variant;
+    int32_t stateless_reward; /* simv1.py:435: nothing carried between steps */
+    int32_t reserved_;
     double goal[3];
 } tto_params;
 
