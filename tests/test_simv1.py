@@ -41,7 +41,7 @@ def test_backward_path_and_pose_generation():
     px, py, pyaw = S.plan_dubins_path_backward(0.0, -10.0, math.pi / 2, 0.0, -30.0, math.pi / 2, 1.0 / 6)
     assert np.abs(px).max() < 1e-9 and (np.diff(py) < 0).all() and np.allclose(pyaw, math.pi / 2)
     assert not S.path_out_of_map(0.0, -10.0, math.pi / 2, 0.0, -30.0, math.pi / 2)
-    assert S.path_out_of_map(39.5, 39.5, 0.0, 0.0, -30.0, math.pi / 2)      # must swing outside the corner
+    assert S.path_out_of_map(39.5, 0.0, math.pi, 0.0, -30.0, math.pi / 2)     # travelling +x at x = 39.5: any radius-6 turn leaves the map
     pool = S.generate_pose_pool(64, seed=3)
     assert pool.shape == (64, 3) and (np.abs(pool[:, :2]) <= 40).all()
     assert (np.hypot(pool[:, 0] - 0.0, pool[:, 1] + 30.0) >= 15).all()     # simv1.py:270-272
