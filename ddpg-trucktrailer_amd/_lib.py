@@ -54,6 +54,9 @@ _SIGNATURES = {
     "tt_env_observe": (C.c_int, [_P, _P, _P, _P]),
     "tt_env_step": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(TTInfo), _I, _P]),
     "tt_env_step_random": (C.c_int, [_P, _U64, _P, _P, _P, _P, C.POINTER(TTInfo), _I, _P]),
+    "tt_env_state_bytes": (C.c_size_t, [_P]),
+    "tt_env_export": (C.c_int, [_P, _P, C.POINTER(C.c_uint64 * 4), _P]),
+    "tt_env_import": (C.c_int, [_P, _P, C.POINTER(C.c_uint64 * 4), _P]),
     "tt_env_rollout_random": (C.c_int, [_P, _I, _U64, _P, _P, _P, _P]),
     "tt_env_profile": (C.c_int, [_P, _I]),
     "tt_env_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -1,0 +1,83 @@
+"""Checkpoint / resume and best-model policy.
+
+The reference saves the four networks' state_dicts (networks.py:70-95; Agent.save_models keeps doing exactly
+that, same file names), a training-state pickle (trainv2.py:210-229) and the last transitions
+(trainv2.py:333-351) -- but not the optimizer state, the env or the replay contents, so a resumed run restarts
+Adam cold.  `save_training_checkpoint` writes ONE torch file with all of it; `BestModelTracker` is the
+reference's "save when best by success rate, then by average score" rule (trainv2.py:538-572)."""
+import numpy as np
+import torch
+
+
+def save_training_checkpoint(path, agent, env=None, ring=None, noise=None, training_state=None, with_replay=True):
+    ck = {"format": 1,
+          "nets": {n: getattr(agent, n).state_dict() for n in ("actor", "critic", "target_actor", "target_critic")},
+          "optim": {"actor": agent.actor.optimizer.state_dict(), "critic": agent.critic.optimizer.state_dict()},
+          "hyper": dict(alpha=agent.alpha, beta=agent.beta, tau=agent.tau, gamma=agent.gamma, batch_size=agent.batch_size),
+          "training_state": training_state or {},
+          "rng": {"torch": torch.get_rng_state(), "numpy": np.random.get_state()[1].tolist()}}
+    if torch.cuda.is_available():
+        ck["rng"]["cuda"] = torch.cuda.get_rng_state()
+    if env is not None:
+        ck["env"] = env.state_dict()
+    if noise is not None:
+        ck["ou"] = noise.x.detach().cpu()
+    if ring is not None:
+        ck["ring"] = {"k": ring.k, "slots": ring.slots, "n": ring.n}
+        if with_replay:
+            ck["ring"].update(obs=ring.obs.cpu(), act=ring.act.cpu(), rew=ring.rew.cpu(), done=ring.done.cpu())
+    torch.save(ck, path)
+    return path
+
+
+def load_training_checkpoint(path, agent, env=None, ring=None, noise=None):
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    for n, sd in ck["nets"].items():
+        getattr(agent, n).load_state_dict(sd)
+    agent.actor.optimizer.load_state_dict(ck["optim"]["actor"])
+    agent.critic.optimizer.load_state_dict(ck["optim"]["critic"])
+    if env is not None and "env" in ck:
+        env.load_state_dict(ck["env"])
+    if noise is not None and "ou" in ck:
+        noise.x.copy_(ck["ou"].to(noise.x.device))
+    if ring is not None and "ring" in ck:
+        r = ck["ring"]
+        assert (r["slots"], r["n"]) == (ring.slots, ring.n), "replay ring geometry differs"
+        if "obs" in r:
+            ring.obs.copy_(r["obs"]); ring.act.copy_(r["act"]); ring.rew.copy_(r["rew"]); ring.done.copy_(r["done"])
+            ring.k = int(r["k"])
+            ring.k_dev.fill_(ring.k)
+    torch.set_rng_state(ck["rng"]["torch"])
+    return ck.get("training_state", {})
+
+
+class BestModelTracker:
+    """trainv2.py:538-572: success_rate over the last 100 episodes; best = higher success rate, or equal success
+    rate and higher 100-episode average score, and only after 100 episodes of this run."""
+
+    def __init__(self, start_episode=0, best_score=-float("inf"), best_success_rate=0.0):
+        self.start_episode = start_episode
+        self.best_score, self.best_success_rate = best_score, best_success_rate
+        self.score_history, self.success_history, self.step_history = [], [], []
+        self.total_steps = 0
+
+    def update(self, episode_index, score, success, steps):
+        """Returns (is_best, avg_score, success_rate); the caller saves models when is_best."""
+        self.total_steps += int(steps)
+        self.score_history.append(float(score))
+        self.step_history.append(self.total_steps)
+        self.success_history.append(1 if success else 0)
+        avg_score = float(np.mean(self.score_history[-100:]))
+        success_rate = float(np.mean(self.success_history[-100:]))
+        better = success_rate > self.best_success_rate
+        equal_better_score = success_rate == self.best_success_rate and avg_score > self.best_score
+        is_best = (better or equal_better_score) and episode_index > (self.start_episode + 100)
+        if is_best:
+            self.best_success_rate, self.best_score = success_rate, avg_score
+        return is_best, avg_score, success_rate
+
+    def training_state(self, episode_num):
+        """The dict trainv2.py:210-229 pickles (same keys)."""
+        return {"episode_num": episode_num, "score_history": list(self.score_history), "best_score": self.best_score,
+                "best_success_rate": self.best_success_rate, "success_history": list(self.success_history),
+                "total_steps": self.total_steps, "step_history": list(self.step_history)}

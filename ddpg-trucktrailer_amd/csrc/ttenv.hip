@@ -1173,6 +1173,40 @@ int tt_env_step_random(tt_env *env, uint64_t policy_seed, float *action_out, flo
     return step_common<true>(env, nullptr, action_out, obs, reward, done, info, auto_reset, policy_seed, stream);
 }
 
+size_t tt_env_state_bytes(const tt_env *env) {
+    if (!env) return 0;
+    const size_t npad = (size_t)env->npad;
+    return sizeof(double) * (H_ROWS + C_ROWS) * npad + sizeof(uint32_t) * npad;
+}
+
+int tt_env_export(tt_env *env, void *blob, uint64_t meta[4], tt_stream_t stream) {
+    if (!env || !blob || !meta) return fail(env, TT_EINVAL, "tt_env_export: NULL argument");
+    TT_HIP(env, hipSetDevice(env->device));
+    const size_t npad = (size_t)env->npad, hb = sizeof(double) * H_ROWS * npad, cb = sizeof(double) * C_ROWS * npad;
+    char *dst = static_cast<char *>(blob);
+    TT_HIP(env, hipMemcpyAsync(dst, env->b.hot, hb, hipMemcpyDeviceToDevice, stream));
+    TT_HIP(env, hipMemcpyAsync(dst + hb, env->b.cold, cb, hipMemcpyDeviceToDevice, stream));
+    TT_HIP(env, hipMemcpyAsync(dst + hb + cb, env->b.episodes, sizeof(uint32_t) * npad, hipMemcpyDeviceToDevice, stream));
+    meta[0] = env->per_env ? 1 : 0; meta[1] = env->seed; meta[2] = (uint64_t)env->n; meta[3] = TT_VERSION;
+    return TT_OK;
+}
+
+int tt_env_import(tt_env *env, const void *blob, const uint64_t meta[4], tt_stream_t stream) {
+    if (!env || !blob || !meta) return fail(env, TT_EINVAL, "tt_env_import: NULL argument");
+    if (meta[2] != (uint64_t)env->n || meta[3] != TT_VERSION)
+        return fail(env, TT_EINVAL, "tt_env_import: blob is for %llu envs (version %llu), handle has %d (version %d)",
+                    (unsigned long long)meta[2], (unsigned long long)meta[3], env->n, TT_VERSION);
+    TT_HIP(env, hipSetDevice(env->device));
+    const size_t npad = (size_t)env->npad, hb = sizeof(double) * H_ROWS * npad, cb = sizeof(double) * C_ROWS * npad;
+    const char *src = static_cast<const char *>(blob);
+    TT_HIP(env, hipMemcpyAsync(env->b.hot, src, hb, hipMemcpyDeviceToDevice, stream));
+    TT_HIP(env, hipMemcpyAsync(env->b.cold, src + hb, cb, hipMemcpyDeviceToDevice, stream));
+    TT_HIP(env, hipMemcpyAsync(env->b.episodes, src + hb + cb, sizeof(uint32_t) * npad, hipMemcpyDeviceToDevice, stream));
+    env->per_env = meta[0] != 0;
+    env->seed = meta[1];
+    return TT_OK;
+}
+
 int tt_env_rollout_random(tt_env *env, int k_steps, uint64_t policy_seed, float *obs_out, float *reward_sum,
                           int32_t *episodes_done, tt_stream_t stream) {
     if (!env) return fail(nullptr, TT_EINVAL, "tt_env_rollout_random: NULL handle");

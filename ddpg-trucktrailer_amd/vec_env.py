@@ -208,6 +208,23 @@ class TruckTrailerVecEnv:
                                                    _ptr(reward_sum), _ptr(episodes_done), self._stream()))
         return obs
 
+    def state_dict(self):
+        """Everything needed to resume this env batch (device blob copied to the host + host-side mode)."""
+        nbytes = int(self.lib.tt_env_state_bytes(self._h))
+        blob = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        meta = (C.c_uint64 * 4)()
+        self._check(self.lib.tt_env_export(self._h, _ptr(blob), C.byref(meta), self._stream()))
+        return {"blob": blob.cpu(), "meta": [int(x) for x in meta], "variant": self.variant,
+                "pool": None if getattr(self, "_pool", None) is None else self._pool.cpu()}
+
+    def load_state_dict(self, sd):
+        blob = sd["blob"].to(self.device)
+        meta = (C.c_uint64 * 4)(*sd["meta"])
+        self._check(self.lib.tt_env_import(self._h, _ptr(blob), C.byref(meta), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()      # blob is a temporary
+        if sd.get("pool") is not None:
+            self.set_reset_pool(sd["pool"])
+
     def profile(self, max_launches):
         """Time the next `max_launches` step-kernel dispatches with per-dispatch HIP events (0 = off)."""
         self._check(self.lib.tt_env_profile(self._h, int(max_launches)))

@@ -157,6 +157,14 @@ int tt_env_step(tt_env *env, const float *action, float *obs, float *reward, uin
 int tt_env_step_random(tt_env *env, uint64_t policy_seed, float *action_out, float *obs, float *reward,
                        uint8_t *done, const tt_info *info, int auto_reset, tt_stream_t stream);
 
+/* Checkpoint / resume of the env batch (the reference only checkpoints networks, trainv2.py:210-244; SURVEY §8f-3
+ * asks for env state too).  The blob is opaque device memory of tt_env_state_bytes(env) bytes holding every
+ * per-env quantity (kinematic state, reward carry, counters, poses, goals, episode numbers); meta[4] carries the
+ * handle's host-side mode {per-env-goal flag, reset seed, n_envs, version}.  Import requires the same n_envs. */
+size_t tt_env_state_bytes(const tt_env *env);
+int tt_env_export(tt_env *env, void *blob, uint64_t meta[4], tt_stream_t stream);
+int tt_env_import(tt_env *env, const void *blob, const uint64_t meta[4], tt_stream_t stream);
+
 /* K vector steps of the random policy in ONE launch (SURVEY.md §8d iii): each env stays in registers for
  * k_steps steps with in-kernel auto-reset; only the last observation is stored.  obs_out [N,23], reward_sum [N]
  * f32 (sum of the k_steps rewards) and episodes_done [N] i32 may each be NULL. */
