@@ -31,6 +31,11 @@ class TTInfo(C.Structure):
     _fields_ = [("comp", C.c_void_p), ("violation", C.c_void_p), ("flags", C.c_void_p)]
 
 
+class TTMlpWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "w3", "b3", "wa", "ba")] + \
+               [("in_dim", C.c_int32), ("fc1_dims", C.c_int32), ("fc2_dims", C.c_int32), ("reserved_", C.c_int32)]
+
+
 class TTError(RuntimeError):
     pass
 
@@ -60,6 +65,10 @@ _SIGNATURES = {
     "tt_env_rollout_random": (C.c_int, [_P, _I, _U64, _P, _P, _P, _P]),
     "tt_env_profile": (C.c_int, [_P, _I]),
     "tt_env_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "tt_actor_forward": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P]),
+    "tt_actor_act": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P, _U64, _U64, _P, C.c_float, C.c_float, C.c_float,
+                               _P, _P, _P, _P]),
+    "tt_critic_forward": (C.c_int, [_I, _P, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_random_actions": (C.c_int, [_I, _U64, _U64, _P, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)

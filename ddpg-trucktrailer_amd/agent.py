@@ -59,6 +59,7 @@ class Agent():
         self.update_network_parameters(tau=1)
         self._critic_params = list(self.critic.parameters())
         self.grad_sync_actor = self.grad_sync_critic = None
+        self.fused_targets = False
         self.last_critic_loss = self.last_actor_loss = None
 
     # ------------------------------------------------------------------ acting (DDPG_agent.py:36-49)
@@ -109,8 +110,13 @@ class Agent():
 
     def learn_batch(self, states, actions, rewards, states_, done):
         with T.no_grad():
-            target_actions = self.target_actor.forward(states_)
-            critic_value_ = self.target_critic.forward(states_, target_actions)
+            if self.fused_targets:      # one fused f32-MFMA launch per target net (csrc/ttnet.hip)
+                from ddpg_trucktrailer_amd import fused
+                target_actions = fused.actor_forward(self.target_actor, states_)
+                critic_value_ = fused.critic_forward(self.target_critic, states_, target_actions)
+            else:
+                target_actions = self.target_actor.forward(states_)
+                critic_value_ = self.target_critic.forward(states_, target_actions)
             critic_value_ = critic_value_.masked_fill(done.view(-1, 1), 0.0).view(-1)      # critic_value_[done] = 0.0
             target = (rewards + self.gamma * critic_value_).view(-1, 1)
         critic_value = self.critic.forward(states, actions)

@@ -47,7 +47,10 @@
 namespace {
 
 constexpr int OBS = TT_OBS_DIM;
-constexpr int BLOCK = 256;
+#ifndef TT_BLOCK
+#define TT_BLOCK 256
+#endif
+constexpr int BLOCK = TT_BLOCK;  // threads per workgroup (a multiple of the 64-env tile)
 constexpr int TILE = 64;
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kDeg = kPi / 180.0;

@@ -1,0 +1,71 @@
+"""Fused f32 inference of the reference-shaped actor / critic (csrc/ttnet.hip) behind torch tensors.
+
+Used where no gradient is needed: the N-env `choose_action` of the rollout loop and the target-network
+forward passes of `learn()`.  Networks of other shapes (or CPU tensors) report `supported(net) == False` and the
+callers use the plain torch modules."""
+import ctypes as C
+import math
+
+import torch
+
+from ddpg_trucktrailer_amd import _lib as L
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def supported(net):
+    return (net.fc1.weight.is_cuda and net.fc1.weight.dtype == torch.float32 and tuple(net.fc1.weight.shape) == (400, 23)
+            and tuple(net.fc2.weight.shape) == (300, 400) and net.bn1.eps == 1e-5 and net.bn2.eps == 1e-5)
+
+
+def weights_of(net):
+    """TTMlpWeights over the module's parameter storages (valid while the parameters are updated in place)."""
+    cached = getattr(net, "_tt_weights", None)
+    key = tuple(p.data_ptr() for p in net.parameters())
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    head = net.mu if hasattr(net, "mu") else net.q
+    w = L.TTMlpWeights()
+    for name, t in (("w1", net.fc1.weight), ("b1", net.fc1.bias), ("g1", net.bn1.weight), ("be1", net.bn1.bias),
+                    ("w2", net.fc2.weight), ("b2", net.fc2.bias), ("g2", net.bn2.weight), ("be2", net.bn2.bias),
+                    ("w3", head.weight), ("b3", head.bias)):
+        assert t.is_contiguous()
+        setattr(w, name, t.data_ptr())
+    if hasattr(net, "action_value"):
+        w.wa, w.ba = net.action_value.weight.data_ptr(), net.action_value.bias.data_ptr()
+    w.in_dim, w.fc1_dims, w.fc2_dims = 23, 400, 300
+    net._tt_weights = (key, w)
+    return w
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def actor_forward(net, obs, out=None):
+    """ActorNetwork.forward without autograd: obs [n,23] f32 -> mu [n,1]."""
+    n = obs.shape[0]
+    out = torch.empty(n, dtype=torch.float32, device=obs.device) if out is None else out
+    L.check(L.load().tt_actor_forward(n, _ptr(obs), C.byref(weights_of(net)), _ptr(out), _stream(obs)))
+    return out.view(n, 1)
+
+
+def critic_forward(net, obs, action, out=None):
+    """CriticNetwork.forward without autograd: obs [n,23], action [n,1] -> q [n,1]."""
+    n = obs.shape[0]
+    out = torch.empty(n, dtype=torch.float32, device=obs.device) if out is None else out
+    L.check(L.load().tt_critic_forward(n, _ptr(obs), _ptr(action), C.byref(weights_of(net)), _ptr(out), _stream(obs)))
+    return out.view(n, 1)
+
+
+def actor_act(net, obs, ou_state, act_raw, act_scaled, seed, step=0, step_dev=None, done_prev=None, mu_out=None,
+              theta=0.2, sigma=0.15, dt=1e-2, high=math.pi / 4):
+    """choose_action + OU noise + clip*high for all rows in one launch (see include/ttenv.h: tt_actor_act)."""
+    n = obs.shape[0]
+    L.check(L.load().tt_actor_act(n, _ptr(obs), C.byref(weights_of(net)), _ptr(ou_state), _ptr(done_prev),
+                                  int(seed) & (2 ** 64 - 1), int(step), _ptr(step_dev), float(theta * dt),
+                                  float(sigma * math.sqrt(dt)), float(high), _ptr(mu_out), _ptr(act_raw),
+                                  _ptr(act_scaled), _stream(obs)))
+    return act_scaled

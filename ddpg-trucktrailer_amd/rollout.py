@@ -13,6 +13,7 @@ import math
 import numpy as np
 import torch
 
+from ddpg_trucktrailer_amd import fused
 from ddpg_trucktrailer_amd.agent import Agent
 from ddpg_trucktrailer_amd.noise import VecOUNoise
 from ddpg_trucktrailer_amd.replay_buffer import TrajectoryRing
@@ -38,13 +39,21 @@ class DDPGRollout:
         self.scaled = torch.zeros(self.n, dtype=torch.float32, device=self.device)
         # the first observation of every env goes into slot 0
         env.observe(out=self.ring.obs[0])
+        self.seed = seed
+        self.fused_act = fused.supported(self.agent.actor)      # csrc/ttnet.hip: reference-shaped 23-400-300-1 actor
+        self.agent.fused_targets = self.fused_act and fused.supported(self.agent.target_critic)
         self.use_graph = use_graph and world_size == 1 and self.device.type == "cuda"
         self.graph = None
         self.vector_steps = 0
 
     # -------------------------------------------------------------- acting
     @torch.no_grad()
-    def act(self, obs, act_out):
+    def act(self, obs, act_out, done_prev=None):
+        if self.fused_act:     # actor forward + OU noise + clip*high in ONE launch (tt_actor_act)
+            return fused.actor_act(self.agent.actor, obs, self.noise.x, act_out, self.scaled, seed=self.seed,
+                                   step=self.vector_steps, done_prev=done_prev, high=self.high)
+        if done_prev is not None:
+            self.noise.reset(done_prev)
         mu = self.agent.actor(obs).view(-1)
         torch.add(mu, self.noise.sample(), out=act_out)                   # stored action: unclipped mu + noise
         torch.clamp(act_out, -1.0, 1.0, out=self.scaled).mul_(self.high)  # what the env is driven with
@@ -80,9 +89,10 @@ class DDPGRollout:
     def step(self):
         ring = self.ring
         t, t1 = ring.slot(), ring.slot(ring.k + 1)
-        scaled = self.act(ring.obs[t], ring.act[t])
+        # the noise of an env whose episode ended at the previous step restarts at 0 (trainv2.py:492)
+        done_prev = ring.done[ring.slot(ring.k - 1)] if ring.k > 0 else None
+        scaled = self.act(ring.obs[t], ring.act[t], done_prev)
         self.env.step(scaled, auto_reset=True, obs_out=ring.obs[t1], reward_out=ring.rew[t], done_out=ring.done[t])
-        self.noise.reset(ring.done[t])
         ring.advance()
         self.learn()
         self.vector_steps += 1

@@ -181,6 +181,32 @@ int tt_env_profile_read(tt_env *env, double *total_ms, int64_t *launches);
 /* "random policy" of BASELINE.json config 2 as a stand-alone action generator: out[i] = U(-1,1) * pi/4 from Philox(seed, step). */
 int tt_random_actions(int n, uint64_t seed, uint64_t step, float *out, tt_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Fused inference of the reference's networks (shapes of trainv2.py:404-407: 23 -> 400 -> 300 -> 1, LayerNorm
+ * eps 1e-5), exact f32 on the f32-input MFMA.  Pointers are torch parameter storages (row-major [out,in]):
+ *   w1 [400,23] b1 g1 be1 [400] = fc1, bn1;  w2 [300,400] b2 g2 be2 [300] = fc2, bn2;  w3 [300] b3 [1] = mu / q;
+ *   wa [300] ba [300] = action_value (critic only).  Other shapes return TT_EINVAL (callers fall back to torch). */
+typedef struct tt_mlp_weights {
+    const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *w3, *b3, *wa, *ba;
+    int32_t in_dim, fc1_dims, fc2_dims, reserved_;
+} tt_mlp_weights;
+
+/* ActorNetwork.forward (DDPG/networks.py:138-147) for n rows: mu_out [n] = tanh(mu(...)). */
+int tt_actor_forward(int n, const float *obs /*[n,23]*/, const tt_mlp_weights *w, float *mu_out, tt_stream_t stream);
+
+/* Agent.choose_action for n envs (DDPG_agent.py:36-49) + OUActionNoise.__call__ (noise.py:13-17) + the caller's
+ * scaling (trainv2.py:516) in one launch: ou_state [n] is advanced in place (x <- x*(1-theta_dt) + sigma_sqrt_dt*N(0,1),
+ * N from Philox(seed, env, step [+ *step_dev]) + Box-Muller; restarted at 0 where done_prev[i] != 0, trainv2.py:492),
+ * act_raw_out [n] = mu + x (the action the replay stores, trainv2.py:525), act_scaled_out [n] = clip(.,-1,1)*high
+ * (what env.step gets).  mu_out and done_prev may be NULL.  step_dev (device int64) may be NULL. */
+int tt_actor_act(int n, const float *obs, const tt_mlp_weights *w, float *ou_state, const uint8_t *done_prev,
+                 uint64_t seed, uint64_t step, const int64_t *step_dev, float theta_dt, float sigma_sqrt_dt, float high,
+                 float *mu_out, float *act_raw_out, float *act_scaled_out, tt_stream_t stream);
+
+/* CriticNetwork.forward (DDPG/networks.py:55-68) for n rows: q_out [n]. */
+int tt_critic_forward(int n, const float *obs /*[n,23]*/, const float *action /*[n]*/, const tt_mlp_weights *w,
+                      float *q_out, tt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

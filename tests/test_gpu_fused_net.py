@@ -1,0 +1,94 @@
+"""GPU (-m gpu): the fused f32-MFMA actor / critic inference kernels (csrc/ttnet.hip) against the plain
+torch modules (f32 reference of the same op), tolerance 2e-5 absolute on tanh outputs / 2e-5 relative on Q."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _nets(dev, seed=0):
+    import torch
+    from ddpg_trucktrailer_amd.networks import ActorNetwork, CriticNetwork
+    torch.manual_seed(seed)
+    a = ActorNetwork(1e-4, (23,), 400, 300, 1, name="actor", device=dev)
+    c = CriticNetwork(1e-3, (23,), 400, 300, 1, name="critic", device=dev)
+    with torch.no_grad():    # non-trivial LayerNorm affine + bigger heads so that mistakes show
+        for net in (a, c):
+            net.bn1.weight.uniform_(0.5, 1.5); net.bn1.bias.uniform_(-0.3, 0.3)
+            net.bn2.weight.uniform_(0.5, 1.5); net.bn2.bias.uniform_(-0.3, 0.3)
+        a.mu.weight.uniform_(-0.2, 0.2); c.q.weight.uniform_(-0.2, 0.2)
+    return a, c
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 1000, 65536])
+def test_actor_and_critic_forward_match_torch(gpu_device, n):
+    import torch
+    from ddpg_trucktrailer_amd import fused
+    actor, critic = _nets(gpu_device)
+    assert fused.supported(actor) and fused.supported(critic)
+    g = torch.Generator(device=gpu_device).manual_seed(n)
+    obs = torch.rand((n, 23), device=gpu_device, generator=g) * 2 - 1
+    act = torch.rand((n, 1), device=gpu_device, generator=g) * 2.4 - 1.2
+    with torch.no_grad():
+        ref_mu, ref_q = actor(obs), critic(obs, act)
+    mu = fused.actor_forward(actor, obs)
+    q = fused.critic_forward(critic, obs, act)
+    assert mu.shape == ref_mu.shape and q.shape == ref_q.shape
+    assert (mu - ref_mu).abs().max().item() <= 2e-5
+    assert (q - ref_q).abs().max().item() <= 2e-5 * max(1.0, ref_q.abs().max().item())
+
+
+def test_real_observations_and_weight_updates_are_seen(gpu_device):
+    """Env observations as input; an in-place optimizer-style update of the weights changes the output."""
+    import torch
+    from ddpg_trucktrailer_amd import fused
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    actor, _ = _nets(gpu_device, seed=3)
+    env = TruckTrailerVecEnv(5000)
+    obs = env.reset(seed=1)
+    with torch.no_grad():
+        ref = actor(obs)
+    assert (fused.actor_forward(actor, obs) - ref).abs().max().item() <= 2e-5
+    with torch.no_grad():
+        actor.fc2.weight.mul_(1.01); actor.mu.bias.add_(0.05)
+        ref2 = actor(obs)
+    out2 = fused.actor_forward(actor, obs)
+    assert (out2 - ref2).abs().max().item() <= 2e-5 and (out2 - ref).abs().max().item() > 1e-3
+    env.close()
+
+
+def test_fused_choose_action_epilogue(gpu_device):
+    import torch
+    from ddpg_trucktrailer_amd import fused
+    actor, _ = _nets(gpu_device, seed=5)
+    n = 40000
+    obs = torch.rand((n, 23), device=gpu_device) * 2 - 1
+    ou = torch.zeros(n, device=gpu_device)
+    raw, scaled, mu = (torch.empty(n, device=gpu_device) for _ in range(3))
+    high = float(np.float32(math.pi / 4))
+    x_prev = ou.clone()
+    draws = []
+    for step in range(6):
+        fused.actor_act(actor, obs, ou, raw, scaled, seed=27, step=step, mu_out=mu, high=high)
+        with torch.no_grad():
+            assert (mu.view(-1, 1) - actor(obs)).abs().max().item() <= 2e-5
+        assert torch.allclose(raw, mu + ou, atol=1e-7)                              # a = mu + noise (DDPG_agent.py:41-45)
+        assert torch.equal(scaled, torch.clamp(raw, -1, 1) * high)                  # trainv2.py:516
+        nrm = (ou - x_prev * (1 - 0.2 * 0.01)) / (0.15 * math.sqrt(0.01))           # the N(0,1) that was drawn
+        draws.append(nrm)
+        x_prev = ou.clone()
+    z = torch.stack(draws)
+    assert abs(z.mean().item()) < 0.01 and abs(z.std().item() - 1) < 0.01
+    assert abs((z ** 4).mean().item() - 3) < 0.1                                    # Gaussian kurtosis
+    assert abs(torch.corrcoef(torch.stack([draws[0], draws[1]]))[0, 1].item()) < 0.02   # steps independent
+    # restart of the noise for finished envs; device-side step counter
+    done = torch.zeros(n, dtype=torch.uint8, device=gpu_device); done[::2] = 1
+    step_dev = torch.tensor(100, dtype=torch.int64, device=gpu_device)
+    before = ou.clone()
+    fused.actor_act(actor, obs, ou, raw, scaled, seed=27, step=0, step_dev=step_dev, done_prev=done, high=high)
+    assert ((ou[::2]).abs() < 0.15 * 0.1 * 6).all() and not torch.equal(ou[1::2], before[1::2])
+    again = before.clone()
+    fused.actor_act(actor, obs, again, raw, scaled, seed=27, step=100, done_prev=done, high=high)
+    assert torch.equal(again, ou)                                                    # step + *step_dev is the counter
