@@ -68,6 +68,7 @@ _SIGNATURES = {
     "tt_actor_forward": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_actor_act": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P, _U64, _U64, _P, C.c_float, C.c_float, C.c_float,
                                _P, _P, _P, _P]),
+    "tt_ring_sample": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _U64, _P, _P, _P, _P, _P, _P, _P]),
     "tt_critic_forward": (C.c_int, [_I, _P, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_random_actions": (C.c_int, [_I, _U64, _U64, _P, _P]),
 }

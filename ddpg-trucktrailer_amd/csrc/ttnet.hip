@@ -267,6 +267,39 @@ __global__ __launch_bounds__(256, 1) void k_mlp_forward(const int n, const float
     }
 }
 
+// Uniform sampling WITH replacement from the trajectory ring (replay_buffer.py:23-34 draws np.random.choice(max_mem,
+// batch)): one workgroup per sampled transition gathers s, a, r, s', done into the batch buffers.  The ring's step
+// counter is read from device memory so that a captured hipGraph of learn() samples fresh indices every replay
+// (the Philox counter includes it).
+__global__ __launch_bounds__(64) void k_ring_sample(const int batch, const int n_envs, const int slots,
+                                                    const long long *__restrict__ k_dev, const float *__restrict__ obs,
+                                                    const float *__restrict__ act, const float *__restrict__ rew,
+                                                    const uint8_t *__restrict__ done, const unsigned long long seed,
+                                                    float *__restrict__ s_out, float *__restrict__ a_out,
+                                                    float *__restrict__ r_out, float *__restrict__ s2_out,
+                                                    uint8_t *__restrict__ d_out, int *__restrict__ idx_out) {
+    const int b = blockIdx.x;
+    if (b >= batch) return;
+    const long long k = *k_dev;                       // vector steps completed; transitions k-avail .. k-1 are intact
+    const long long avail = k < slots - 1 ? k : slots - 1;
+    uint32_t r[4];
+    philox4x32((uint32_t)b, (uint32_t)k, (uint32_t)(k >> 32), 0x5A3Du, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const long long back = avail > 0 ? (long long)(((unsigned long long)r[0] * (unsigned long long)avail) >> 32) : 0;
+    const int t = (int)(((k - 1 - back) % slots + slots) % slots), t1 = (t + 1) % slots;
+    const int e = (int)(((unsigned long long)r[1] * (unsigned long long)n_envs) >> 32);
+    const int lane = threadIdx.x;
+    const float *src = obs + ((size_t)t * n_envs + e) * IN, *src2 = obs + ((size_t)t1 * n_envs + e) * IN;
+    if (lane < IN) s_out[(size_t)b * IN + lane] = src[lane];
+    else if (lane >= 32 && lane < 32 + IN) s2_out[(size_t)b * IN + lane - 32] = src2[lane - 32];
+    if (lane == 63) {
+        const size_t q = (size_t)t * n_envs + e;
+        a_out[b] = act[q];
+        r_out[b] = rew[q];
+        d_out[b] = done[q];
+        if (idx_out) { idx_out[2 * b] = t; idx_out[2 * b + 1] = e; }
+    }
+}
+
 int check_ptrs(const tt_mlp_weights *w, bool critic) {
     if (!w) return 0;
     if (w->in_dim != IN || w->fc1_dims != H1 || w->fc2_dims != H2) return 0;
@@ -316,6 +349,19 @@ int tt_actor_act(int n, const float *obs, const tt_mlp_weights *w, float *ou_sta
     act.seed = seed; act.step = step;
     act.decay = 1.0f - theta_dt; act.scale = sigma_sqrt_dt; act.high = high;
     return launch<false>(n, obs, nullptr, w, mu_out, act, stream);
+}
+
+int tt_ring_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const float *obs, const float *act,
+                   const float *rew, const uint8_t *done, uint64_t seed, float *s_out, float *a_out, float *r_out,
+                   float *s2_out, uint8_t *d_out, int32_t *idx_out, tt_stream_t stream) {
+    if (batch < 0 || n_envs <= 0 || slots < 3 || !k_dev || !obs || !act || !rew || !done || !s_out || !a_out || !r_out ||
+        !s2_out || !d_out)
+        return TT_EINVAL;
+    if (batch == 0) return TT_OK;
+    hipLaunchKernelGGL(k_ring_sample, dim3(batch), dim3(64), 0, stream, batch, n_envs, slots,
+                       reinterpret_cast<const long long *>(k_dev), obs, act, rew, done, seed, s_out, a_out, r_out, s2_out,
+                       d_out, idx_out);
+    return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 
 int tt_critic_forward(int n, const float *obs, const float *action, const tt_mlp_weights *w, float *q_out,

@@ -79,6 +79,24 @@ class TrajectoryRing:
         self.k += 1
         self.k_dev += 1
 
+    def sample_fused(self, batch_size, seed=0, return_index=False):
+        """sample() as ONE HIP launch (tt_ring_sample): Philox indices keyed by (seed, k_dev) + gather."""
+        import ctypes as C
+        from ddpg_trucktrailer_amd import _lib as L
+        if getattr(self, "_bufs", None) is None or self._bufs[0].shape[0] != batch_size:
+            f = dict(dtype=torch.float32, device=self.device)
+            d = self.obs.shape[2]
+            self._bufs = (torch.empty((batch_size, d), **f), torch.empty((batch_size, 1), **f), torch.empty(batch_size, **f),
+                          torch.empty((batch_size, d), **f), torch.empty(batch_size, dtype=torch.uint8, device=self.device),
+                          torch.empty((batch_size, 2), dtype=torch.int32, device=self.device))
+        s, a, r, s2, dn, idx = self._bufs
+        p = lambda t: C.c_void_p(t.data_ptr())
+        L.check(L.load().tt_ring_sample(batch_size, self.n, self.slots, p(self.k_dev), p(self.obs), p(self.act), p(self.rew),
+                                        p(self.done), int(seed) & (2 ** 64 - 1), p(s), p(a), p(r), p(s2), p(dn), p(idx),
+                                        C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        out = (s, a, r, s2, dn.bool())
+        return out + (idx,) if return_index else out
+
     def sample(self, batch_size, generator=None):
         """Uniform with replacement over the stored transitions; index math on the device (k_dev), so the call
         can sit inside a captured hipGraph."""

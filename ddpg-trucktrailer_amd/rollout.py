@@ -61,7 +61,10 @@ class DDPGRollout:
 
     # -------------------------------------------------------------- learning
     def _learn_once(self):
-        s, a, r, s2, d = self.ring.sample(self.batch_size)
+        if self.device.type == "cuda":
+            s, a, r, s2, d = self.ring.sample_fused(self.batch_size, seed=self.seed)
+        else:
+            s, a, r, s2, d = self.ring.sample(self.batch_size)
         self.agent.learn_batch(s, a, r, s2, d)
 
     def learn(self):

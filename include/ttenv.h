@@ -203,6 +203,15 @@ int tt_actor_act(int n, const float *obs, const tt_mlp_weights *w, float *ou_sta
                  uint64_t seed, uint64_t step, const int64_t *step_dev, float theta_dt, float sigma_sqrt_dt, float high,
                  float *mu_out, float *act_raw_out, float *act_scaled_out, tt_stream_t stream);
 
+/* ReplayBuffer.sample_buffer (DDPG/replay_buffer.py:23-34: uniform WITH replacement) on the device trajectory ring
+ * obs [slots,N,23] f32, act/rew [slots,N] f32, done [slots,N] u8 (transition (t,e) = obs[t][e], act[t][e], rew[t][e],
+ * obs[t+1][e], done[t][e]); *k_dev = vector steps completed, read on the device, so a captured hipGraph draws new
+ * indices at every replay.  Outputs: s_out, s2_out [batch,23], a_out, r_out [batch] f32, d_out [batch] u8,
+ * idx_out [batch,2] i32 (slot, env) or NULL. */
+int tt_ring_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const float *obs, const float *act,
+                   const float *rew, const uint8_t *done, uint64_t seed, float *s_out, float *a_out, float *r_out,
+                   float *s2_out, uint8_t *d_out, int32_t *idx_out, tt_stream_t stream);
+
 /* CriticNetwork.forward (DDPG/networks.py:55-68) for n rows: q_out [n]. */
 int tt_critic_forward(int n, const float *obs /*[n,23]*/, const float *action /*[n]*/, const tt_mlp_weights *w,
                       float *q_out, tt_stream_t stream);

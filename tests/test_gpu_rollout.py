@@ -115,3 +115,40 @@ def test_graph_learn_equals_eager_learn(gpu_device):
     for name in ("actor", "critic", "target_actor", "target_critic"):
         for (k, x), y in zip(getattr(eager, name).state_dict().items(), getattr(graphed, name).state_dict().values()):
             assert torch.allclose(x, y, rtol=1e-5, atol=1e-7), (name, k)
+
+
+def test_fused_ring_sampling(gpu_device):
+    """tt_ring_sample: every drawn transition is intact ring content, indices are uniform over the valid window,
+    and consecutive replays (k_dev advanced) draw different indices."""
+    import torch
+    from ddpg_trucktrailer_amd.replay_buffer import TrajectoryRing
+    n, slots, B = 1000, 6, 4096
+    ring = TrajectoryRing(n, slots, 23, gpu_device)
+    for k in range(9):
+        t, t1 = ring.slot(), ring.slot(ring.k + 1)
+        if k == 0:
+            ring.obs[t].fill_(0.0)
+        lane = torch.arange(n, device=gpu_device, dtype=torch.float32)
+        ring.act[t] = k * 10000 + lane
+        ring.rew[t] = -(k * 10000 + lane)
+        ring.done[t] = ((torch.arange(n, device=gpu_device) + k) % 7 == 0).to(torch.uint8)
+        ring.obs[t1] = (k + 1) + lane.unsqueeze(1) / 4096 + torch.arange(23, device=gpu_device) / 100000
+        ring.advance()
+        s, a, r, s2, d, idx = ring.sample_fused(B, seed=5, return_index=True)
+        step = torch.div(a[:, 0], 10000, rounding_mode="floor")
+        e = a[:, 0] - step * 10000
+        assert torch.equal(r, -a[:, 0])
+        assert step.min() >= max(0, k - (slots - 2)) and step.max() <= k
+        if k >= 1:
+            ok = step >= 1
+            assert torch.allclose(s[ok][:, 0], step[ok] + e[ok] / 4096, atol=1e-4)
+        assert torch.allclose(s2[:, 0], step + 1 + e / 4096, atol=1e-4)
+        assert torch.equal(d, ((e.long() + step.long()) % 7 == 0))
+        assert torch.equal(idx[:, 1].long(), e.long()) and torch.equal(idx[:, 0].long(), step.long() % slots)
+    # uniformity over envs and over the 5 valid steps
+    hist_e = torch.bincount(idx[:, 1].long() // 100, minlength=10).float()
+    hist_t = torch.bincount((step - step.min()).long(), minlength=slots - 1).float()
+    assert (hist_e / B - 0.1).abs().max() < 0.03 and (hist_t / B - 0.2).abs().max() < 0.04
+    again = ring.sample_fused(B, seed=5, return_index=True)[5].clone()
+    ring.advance()
+    assert not torch.equal(again, ring.sample_fused(B, seed=5, return_index=True)[5])
