@@ -39,6 +39,50 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(n):
+    """HBM bytes per k_step launch from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    bench.py cannot collect counters itself; null when the summary is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return float(json.load(f)["traffic_B_per_env_step"]) * n
+    except Exception:
+        return None
+
+
+def cpu_full_loop(seconds=6.0, batch=256):
+    """The reference's whole training loop shape on the host: twin env step + choose_action + remember + learn()
+    (torch CPU, batch 256 as in BASELINE config 3), one process."""
+    import numpy as np
+    import torch
+    from ddpg_trucktrailer_amd.agent import Agent
+    from oracle.simv2_twin import Simv2Twin
+    env = Simv2Twin()
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(min(8, threads_before))     # more threads only slow these 256-row kernels down
+    agent = Agent(alpha=1e-4, beta=1e-3, input_dims=(23,), tau=1e-3, n_actions=1, batch_size=batch, device="cpu",
+                  max_size=100000)
+    obs, _ = env.reset(seed=0)
+    high = np.float32(np.pi / 4)
+    n, t0 = 0, None
+    while True:
+        a = agent.choose_action(obs)
+        obs2, r, done, _ = env.step(np.clip(a, -1, 1) * high)
+        agent.remember(obs, a, r, obs2, done)
+        agent.learn()
+        obs = env.reset()[0] if done else obs2
+        n += 1
+        if t0 is None and n == batch + 20:      # learn() is live from step `batch` on
+            t0, n0 = time.perf_counter(), n
+        if t0 is not None and time.perf_counter() - t0 > seconds:
+            break
+    dt = time.perf_counter() - t0
+    used = torch.get_num_threads()
+    torch.set_num_threads(threads_before)
+    return {"value": (n - n0) / dt, "unit": "env-steps/s", "cores": used,
+            "sample": f"{n - n0} iterations of twin env.step + choose_action + remember + learn(batch {batch}) on torch CPU, {dt:.1f} s"}
+
+
 def cpu_baseline(seconds):
     """Oracle timed on the host cores (rank 0, N=1 only): the structure-faithful Python/scipy twin of the
     reference's step loop on ONE core (the reference is single-threaded), random policy, reset on done.
@@ -68,6 +112,7 @@ def cpu_baseline(seconds):
     return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": f"{n} steps of oracle/simv2_twin.py (numpy + scipy solve_ivp RK45 + reward object per step), "
                       f"uniform-random steering, reset on done, {dt:.1f} s",
+            "full_loop": cpu_full_loop(),
             "c_port": {"value": cn / cdt, "unit": "env-steps/s", "cores": cores,
                        "sample": f"{cn} steps of oracle/tt_oracle.c (fixed DP5, OpenMP), {cdt:.2f} s"}}
 
@@ -172,7 +217,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": dict({"workload": workload, "n_envs_per_gpu": n, "n_envs_total": n * world}, **extra),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_step",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n), "kernel": "k_step",
                      "kernel_ms": kern_ms, "alg_bytes_per_env_step": B_ALG,
                      "kernel_env_steps_per_s": n / (kern_ms * 1e-3)},
     }
