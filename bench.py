@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-graph", action="store_true", help="run learn() eagerly instead of as a hipGraph")
+    ap.add_argument("--torch-learn", action="store_true", help="learn() through torch autograd instead of the fused HIP kernels")
     ap.add_argument("--graph-steps", type=int, default=50, help="env workload: vector steps per captured hipGraph")
     return ap.parse_args()
 
@@ -170,7 +171,7 @@ def main():
     else:
         from ddpg_trucktrailer_amd.rollout import DDPGRollout
         loop = DDPGRollout(env, batch_size=args.batch, replay_slots=args.replay_slots, seed=27 + rank,
-                           world_size=world, use_graph=not args.no_graph)
+                           world_size=world, use_graph=not args.no_graph, fused_learn=not args.torch_learn)
 
         def one_step(timed):
             loop.step()

@@ -36,6 +36,14 @@ class TTMlpWeights(C.Structure):
                [("in_dim", C.c_int32), ("fc1_dims", C.c_int32), ("fc2_dims", C.c_int32), ("reserved_", C.c_int32)]
 
 
+class TTMlpSaved(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("xh1", "h1", "xh2", "h2", "rstd1", "rstd2")]
+
+
+class TTMlpBwdWs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dpre", "dz", "dx2", "dy1", "dx1")]
+
+
 class TTError(RuntimeError):
     pass
 
@@ -70,6 +78,12 @@ _SIGNATURES = {
                                _P, _P, _P, _P]),
     "tt_ring_sample": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _U64, _P, _P, _P, _P, _P, _P, _P]),
     "tt_critic_forward": (C.c_int, [_I, _P, _P, C.POINTER(TTMlpWeights), _P, _P]),
+    "tt_mlp_forward_save": (C.c_int, [_I, _I, _P, _P, C.POINTER(TTMlpWeights), _P, C.POINTER(TTMlpSaved), _P, _P]),
+    "tt_mlp_backward": (C.c_int, [_I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, C.POINTER(TTMlpWeights),
+                                  C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights), _P]),
+    "tt_adam_soft_update": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
+                                      C.c_float, C.c_float, _P]),
+    "tt_td_target": (C.c_int, [_I, _P, _P, _P, C.c_float, _P, _P, _P]),
     "tt_random_actions": (C.c_int, [_I, _U64, _U64, _P, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -60,6 +60,7 @@ class Agent():
         self._critic_params = list(self.critic.parameters())
         self.grad_sync_actor = self.grad_sync_critic = None
         self.fused_targets = False
+        self.fused_learner = None      # set by DDPGRollout when learn() runs on the hand-fused kernels
         self.last_critic_loss = self.last_actor_loss = None
 
     # ------------------------------------------------------------------ acting (DDPG_agent.py:36-49)

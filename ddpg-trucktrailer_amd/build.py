@@ -6,7 +6,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", "ttenv.hip"), os.path.join(HERE, "csrc", "ttnet.hip")]
+SRC = [os.path.join(HERE, "csrc", "ttenv.hip"), os.path.join(HERE, "csrc", "ttnet.hip"),
+       os.path.join(HERE, "csrc", "ttlearn.hip")]
 HDR = [os.path.join(ROOT, "include", "ttenv.h")]
 LIB = os.path.join(HERE, "libttenv.so")
 

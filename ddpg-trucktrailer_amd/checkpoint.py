@@ -10,6 +10,8 @@ import torch
 
 
 def save_training_checkpoint(path, agent, env=None, ring=None, noise=None, training_state=None, with_replay=True):
+    if getattr(agent, "fused_learner", None) is not None:
+        agent.fused_learner.export_to_optimizers()          # Adam moments live in the fused learner's flat buffers
     ck = {"format": 1,
           "nets": {n: getattr(agent, n).state_dict() for n in ("actor", "critic", "target_actor", "target_critic")},
           "optim": {"actor": agent.actor.optimizer.state_dict(), "critic": agent.critic.optimizer.state_dict()},
@@ -36,6 +38,8 @@ def load_training_checkpoint(path, agent, env=None, ring=None, noise=None):
         getattr(agent, n).load_state_dict(sd)
     agent.actor.optimizer.load_state_dict(ck["optim"]["actor"])
     agent.critic.optimizer.load_state_dict(ck["optim"]["critic"])
+    if getattr(agent, "fused_learner", None) is not None:
+        agent.fused_learner.import_from_optimizers()
     if env is not None and "env" in ck:
         env.load_state_dict(ck["env"])
     if noise is not None and "ou" in ck:

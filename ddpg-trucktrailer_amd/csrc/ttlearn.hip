@@ -1,0 +1,768 @@
+// ttlearn.hip -- hand-fused DDPG learn() for the reference-shaped networks (23 -> 400 -> LN -> ReLU -> 300 -> LN ...),
+// exact f32, MI355X (gfx950).  What DDPG_agent.learn() (DDPG/DDPG_agent.py:72-106) does through ~140 autograd
+// kernels at batch 256 is done here in about a dozen launches:
+//
+//   k_fwd_small<CRITIC>   forward of one net on the batch, saving what its backward needs (normalised
+//                         pre-activations, 1/sigma, post-ReLU activations); for the critic optionally dQ/da
+//   k_bwd_rows<CRITIC>    per-row backward: head -> ReLU -> LayerNorm2 -> dH1 = dX2 * W2 (MFMA) -> ReLU -> LayerNorm1
+//   k_bwd_weights         dW2 = dX2^T * H1 and dW1 = dX1^T * S on the MFMA (K = batch), all bias / LayerNorm / head
+//                         gradients as deterministic column sums (no atomics)
+//   k_adam_soft           torch.optim.Adam's update (L2 weight decay in the gradient) + the soft target update
+//
+// Small-batch geometry: a workgroup owns 16 rows; its 4 waves split the output COLUMNS (so a 256-row batch is 16
+// workgroups x 4 waves instead of 4 x 4), and LayerNorm statistics are combined across the waves through LDS.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ttenv.h"
+
+namespace {
+
+constexpr int IN = 23, INP = 24;
+constexpr int H1 = 400, H2 = 300, H2P = 320, H2K = 304;   // H2K: fc2 outputs rounded up to whole k16 steps
+constexpr int NT1 = H1 / 16, NT2 = H2P / 16;
+constexpr int TR = 16;                    // rows per workgroup
+constexpr int HS1 = 404;                  // LDS row stride of the 16 x 400 activation tile: 16-byte rows, and 404 mod 64 = 20
+                                          // spreads the 16 rows of a ds_read_b128 fragment over all 64 banks
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct Weights {
+    const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *w3, *b3, *wa, *ba;
+};
+struct Saved {          // forward activations kept for the backward (all [B, .] row-major f32)
+    float *xh1, *h1;    // [B,400] normalised fc1 output (before gamma/beta), post-ReLU activation
+    float *xh2, *h2;    // [B,300] normalised fc2 output, post-ReLU activation (critic: after + action_value)
+    float *rstd1, *rstd2;   // [B]
+};
+
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+// combine a per-wave, per-row partial (valid in every lane of the 16-lane group of that row) across the 4 waves.
+// red: [4 waves][16 rows].  Two barriers; every lane returns the total of ITS four rows (r = 0..3).
+__device__ __forceinline__ void cross_wave_sum(float *red, int wave, int l4, int l15, float (&v)[4]) {
+    __syncthreads();                       // previous use of `red` is over
+    if (l15 == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * TR + l4 * 4 + r] = v[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = l4 * 4 + r;
+        v[r] = red[row] + red[TR + row] + red[2 * TR + row] + red[3 * TR + row];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// MFMA operand convention used by every product below.  v_mfma_f32_16x16x4_f32 sums over 4 values of k per
+// instruction and lane l supplies k_local = l >> 4.  A dot product does not care in which ORDER k is visited, so one
+// "k16 step" (16 consecutive k) is issued as 4 MFMAs where lane l contributes k = k0 + 4*(l>>4) + ks in MFMA ks:
+// the four values a lane needs are then CONTIGUOUS in memory and arrive as one 16-byte load (global float4 or
+// ds_read_b128) instead of four 4-byte ones.  Weights are read straight from L2 this way (no LDS ring, no
+// barriers inside the K loops), so the loads of many steps can be in flight at once.
+// The same trick on the N side ("column group"): lane l loads float4 W[k][c0 + 4*(l&15) .. +3] and uses component t
+// as the B operand of output tile t, whose 16 columns are c0 + 4*(l&15) + t.
+
+// forward on a small batch.  out [B]: q (critic) or mu = tanh(.) (actor).  dq_da [B] (critic, optional):
+// dQ/da = sum_j wq[j] * [z_j > 0] * wa[j], which is all of the critic the actor's gradient needs because the action
+// enters after LayerNorm2 (networks.py:62-66).
+template <bool CRITIC>
+__global__ __launch_bounds__(256) void k_fwd_small(const int n, const float *__restrict__ obs,
+                                                   const float *__restrict__ action, const Weights W,
+                                                   float *__restrict__ out, const Saved sv, float *__restrict__ dq_da) {
+    __shared__ __attribute__((aligned(16))) float h1_s[TR * HS1];     // [16][404]: A operand of layer 2
+    __shared__ float red[4 * TR];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int row0 = blockIdx.x * TR;
+
+    // ---- layer 1 (K = 23): operands straight from global; this wave's column tiles t = wave, wave+4, ...
+    constexpr int MT1 = 7;
+    f32x4 acc1[MT1];
+#pragma unroll
+    for (int i = 0; i < MT1; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        float a[INP / 4];
+#pragma unroll
+        for (int ks = 0; ks < INP / 4; ++ks) {
+            const int k = ks * 4 + l4;
+            a[ks] = (k < IN && row0 + l15 < n) ? obs[(size_t)(row0 + l15) * IN + k] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < MT1; ++i) {
+            const int t = wave + 4 * i;
+            if (t < NT1) {
+                float b[INP / 4];
+#pragma unroll
+                for (int ks = 0; ks < INP / 4; ++ks) {
+                    const int k = ks * 4 + l4;
+                    b[ks] = k < IN ? W.w1[(t * 16 + l15) * IN + k] : 0.f;
+                }
+#pragma unroll
+                for (int ks = 0; ks < INP / 4; ++ks) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b[ks], acc1[i], 0, 0, 0);
+            }
+        }
+    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MT1; ++i) {
+        const int t = wave + 4 * i;
+        if (t < NT1) {
+            const float bias = W.b1[t * 16 + l15];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc1[i][r] += bias; s[r] += acc1[i][r]; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = row_sum16(s[r]);
+    cross_wave_sum(red, wave, l4, l15, s);
+    float mean[4], rstd[4], ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mean[r] = s[r] * (1.f / H1);
+#pragma unroll
+    for (int i = 0; i < MT1; ++i) {
+        if (wave + 4 * i < NT1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = acc1[i][r] - mean[r]; ss[r] = fmaf(d, d, ss[r]); }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ss[r] = row_sum16(ss[r]);
+    cross_wave_sum(red, wave, l4, l15, ss);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rstd[r] = rsqrtf(ss[r] * (1.f / H1) + 1e-5f);
+    if (sv.rstd1 && wave == 0 && l15 == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (row0 + l4 * 4 + r < n) sv.rstd1[row0 + l4 * 4 + r] = rstd[r];
+    }
+#pragma unroll
+    for (int i = 0; i < MT1; ++i) {
+        const int t = wave + 4 * i;
+        if (t < NT1) {
+            const int col = t * 16 + l15;
+            const float g = W.g1[col], be = W.be1[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = l4 * 4 + r;
+                const float xh = (acc1[i][r] - mean[r]) * rstd[r];
+                const float h = fmaxf(fmaf(xh, g, be), 0.f);
+                h1_s[lr * HS1 + col] = h;
+                if (sv.xh1 && row0 + lr < n) {
+                    sv.xh1[(size_t)(row0 + lr) * H1 + col] = xh;
+                    sv.h1[(size_t)(row0 + lr) * H1 + col] = h;
+                }
+            }
+        }
+    }
+    __syncthreads();   // the 16 x 400 activation tile is complete
+
+    // ---- layer 2: this wave's 5 column tiles; A from the LDS tile (one ds_read_b128 per k16 step), B = fc2 rows
+    // straight from L2 (one float4 per tile per k16 step), k visited in the permuted order described above
+    constexpr int MT2 = NT2 / 4;
+    f32x4 acc2[MT2];
+#pragma unroll
+    for (int i = 0; i < MT2; ++i) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *wrow[MT2];
+    bool wreal[MT2];
+#pragma unroll
+    for (int i = 0; i < MT2; ++i) {
+        const int nn = (wave * MT2 + i) * 16 + l15;
+        wreal[i] = nn < H2;
+        wrow[i] = W.w2 + (size_t)(wreal[i] ? nn : 0) * H1 + 4 * l4;
+    }
+    const float *arow = h1_s + l15 * HS1 + 4 * l4;
+    // software pipeline: the B fragments of super-step ss+1 (5 k16 steps x 5 tiles = 25 float4 per lane) are in
+    // flight from L2 while the 100 MFMAs of super-step ss issue
+    constexpr int SS = 5;
+    struct BFrag { float4 v[SS][MT2]; };
+    auto load_b = [&](int ss) {
+        BFrag f;
+#pragma unroll
+        for (int st = 0; st < SS; ++st)
+#pragma unroll
+            for (int i = 0; i < MT2; ++i) {
+                f.v[st][i] = *reinterpret_cast<const float4 *>(wrow[i] + 16 * (ss * SS + st));
+                if (!wreal[i]) f.v[st][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        return f;
+    };
+    BFrag cur = load_b(0);
+#pragma unroll
+    for (int ss = 0; ss < H1 / 16 / SS; ++ss) {
+        BFrag nxt = cur;
+        if (ss + 1 < H1 / 16 / SS) nxt = load_b(ss + 1);
+#pragma unroll
+        for (int st = 0; st < SS; ++st) {
+            const float4 av = *reinterpret_cast<const float4 *>(arow + 16 * (ss * SS + st));
+            // ks-major: consecutive MFMAs write different accumulators (dependent latency 40 > issue 32 cycles)
+#pragma unroll
+            for (int i = 0; i < MT2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, cur.v[st][i].x, acc2[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, cur.v[st][i].y, acc2[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, cur.v[st][i].z, acc2[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, cur.v[st][i].w, acc2[i], 0, 0, 0);
+        }
+        cur = nxt;
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT2; ++i) {
+        const int col = (wave * MT2 + i) * 16 + l15;
+        const bool real = col < H2;
+        const float bias = real ? W.b2[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc2[i][r] = real ? acc2[i][r] + bias : 0.f; s[r] += acc2[i][r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[r] = row_sum16(s[r]);
+    cross_wave_sum(red, wave, l4, l15, s);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mean[r] = s[r] * (1.f / H2); ss[r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < MT2; ++i) {
+        const bool real = (wave * MT2 + i) * 16 + l15 < H2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = real ? acc2[i][r] - mean[r] : 0.f; ss[r] = fmaf(d, d, ss[r]); }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ss[r] = row_sum16(ss[r]);
+    cross_wave_sum(red, wave, l4, l15, ss);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rstd[r] = rsqrtf(ss[r] * (1.f / H2) + 1e-5f);
+    if (sv.rstd2 && wave == 0 && l15 == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (row0 + l4 * 4 + r < n) sv.rstd2[row0 + l4 * 4 + r] = rstd[r];
+    }
+    float av[4] = {0.f, 0.f, 0.f, 0.f};
+    if (CRITIC) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + l4 * 4 + r;
+            av[r] = row < n ? action[row] : 0.f;
+        }
+    }
+    float dot[4] = {0.f, 0.f, 0.f, 0.f}, dqa[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MT2; ++i) {
+        const int col = (wave * MT2 + i) * 16 + l15;
+        if (col < H2) {
+            const float g = W.g2[col], be = W.be2[col], w3 = W.w3[col];
+            float wa = 0.f, ba = 0.f;
+            if (CRITIC) { wa = W.wa[col]; ba = W.ba[col]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = l4 * 4 + r;
+                const float xh = (acc2[i][r] - mean[r]) * rstd[r];
+                float z = fmaf(xh, g, be);
+                if (CRITIC) z += fmaf(av[r], wa, ba);
+                const float h = fmaxf(z, 0.f);
+                dot[r] = fmaf(h, w3, dot[r]);
+                if (CRITIC) dqa[r] = fmaf(z > 0.f ? w3 : 0.f, wa, dqa[r]);
+                if (sv.xh2 && row0 + lr < n) {
+                    sv.xh2[(size_t)(row0 + lr) * H2 + col] = xh;
+                    sv.h2[(size_t)(row0 + lr) * H2 + col] = h;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dot[r] = row_sum16(dot[r]);
+    cross_wave_sum(red, wave, l4, l15, dot);
+    if (CRITIC && dq_da) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dqa[r] = row_sum16(dqa[r]);
+        cross_wave_sum(red, wave, l4, l15, dqa);
+    }
+    if (wave == 0 && l15 == 0) {
+        const float b3 = W.b3[0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + l4 * 4 + r;
+            if (row < n) {
+                const float v = dot[r] + b3;
+                out[row] = CRITIC ? v : tanhf(v);
+                if (CRITIC && dq_da) dq_da[row] = dqa[r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// per-row backward of one net.  16 rows per workgroup.
+//   mode 0: d_out[b] is given (gradient w.r.t. `out`)
+//   mode 1: d_out[b] = scale * (out[b] - y[b])          critic MSE: d/dq mean((y - q)^2), scale = 2/B
+//   mode 2: d_out[b] = scale * aux[b]                    actor: d/dmu mean(-Q), aux = dQ/da, scale = -1/B
+// actor (CRITIC = false): `out` is mu = tanh(pre) and the head gradient is d_out * (1 - mu^2).
+// Writes dpre [B], dz [B,300] (grad at the ReLU-masked LayerNorm2 output), dx2 [B,300] (grad at fc2's output),
+// dy1 [B,400] (grad at the ReLU-masked LayerNorm1 output), dx1 [B,400] (grad at fc1's output).
+constexpr int DS = 308;                       // LDS row stride of the dX2 tile (A operand, K = 304; 16-byte rows)
+constexpr int NG = 7;                         // 64-column groups covering the 400 columns of dH1 (the last is partial)
+
+struct BwdOut {
+    float *dpre, *dz, *dx2, *dy1, *dx1;
+};
+
+__device__ __forceinline__ float wave_sum64(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+template <bool CRITIC>
+__global__ __launch_bounds__(256) void k_bwd_rows(const int n, const int mode, const float scale,
+                                                  const float *__restrict__ d_out, const float *__restrict__ out,
+                                                  const float *__restrict__ y, const float *__restrict__ aux,
+                                                  const Weights W, const Saved sv, const BwdOut o) {
+    __shared__ __attribute__((aligned(16))) float dx2_s[TR * DS];    // [16][308]
+    __shared__ float red[4 * TR];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int row0 = blockIdx.x * TR;
+
+    // ---- phase A: head, ReLU and LayerNorm2 backward; wave w owns rows 4w .. 4w+3, lanes stride the 300 columns
+    for (int rr = 0; rr < 4; ++rr) {
+        const int lr = wave * 4 + rr, row = row0 + lr;
+        float dpre = 0.f;
+        if (row < n) {
+            float g = mode == 0 ? d_out[row] : (mode == 1 ? scale * (out[row] - y[row]) : scale * aux[row]);
+            if (!CRITIC) { const float mu = out[row]; g *= (1.f - mu * mu); }
+            dpre = g;
+        }
+        float dxh[5], xh[5], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = lane + 64 * i;
+            dxh[i] = 0.f; xh[i] = 0.f;
+            if (c < H2 && row < n) {
+                const size_t q = (size_t)row * H2 + c;
+                const float dz = sv.h2[q] > 0.f ? dpre * W.w3[c] : 0.f;
+                o.dz[q] = dz;
+                xh[i] = sv.xh2[q];
+                dxh[i] = dz * W.g2[c];
+                s1 += dxh[i];
+                s2 = fmaf(dxh[i], xh[i], s2);
+            }
+        }
+        s1 = wave_sum64(s1) * (1.f / H2);
+        s2 = wave_sum64(s2) * (1.f / H2);
+        const float rs = row < n ? sv.rstd2[row] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = lane + 64 * i;
+            if (c < DS) {
+                float v = 0.f;
+                if (c < H2 && row < n) {
+                    v = rs * (dxh[i] - s1 - xh[i] * s2);
+                    o.dx2[(size_t)row * H2 + c] = v;
+                }
+                dx2_s[lr * DS + c] = v;                     // zero in the K padding (columns 300..307)
+            }
+        }
+        if (lane == 0 && row < n) o.dpre[row] = dpre;
+    }
+    __syncthreads();
+
+    // ---- phase B: dH1 [16,400] = dX2 [16,304] * W2 [304,400].  Wave w owns the 64-column groups w and w+4; within a
+    // group, output tile t holds columns c0 + 4*(l&15) + t (one float4 of a W2 row feeds the 4 tiles).
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *arow = dx2_s + l15 * DS + 4 * l4;
+    // software pipeline over groups of 3 k16 steps: 24 float4 rows of fc2 per lane in flight while 96 MFMAs issue
+    constexpr int GS = 3, NGRP = (H2K / 16 + GS - 1) / GS;        // 19 steps -> 7 groups (the last holds 1)
+    struct BFrag { float4 v[GS][4][2]; };
+    const bool gok[2] = {wave < NG && wave * 64 + 4 * l15 < H1, wave + 4 < NG && (wave + 4) * 64 + 4 * l15 < H1};
+    const float *wcol[2] = {W.w2 + (gok[0] ? wave * 64 + 4 * l15 : 0), W.w2 + (gok[1] ? (wave + 4) * 64 + 4 * l15 : 0)};
+    auto load_b = [&](int grp) {
+        BFrag f;
+#pragma unroll
+        for (int st = 0; st < GS; ++st)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int j = 16 * (grp * GS + st) + 4 * l4 + ks;      // row of fc2 = the k of this product
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    f.v[st][ks][g] = (gok[g] && j < H2) ? *reinterpret_cast<const float4 *>(wcol[g] + (size_t)j * H1)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        return f;
+    };
+    BFrag cur = load_b(0);
+#pragma unroll
+    for (int grp = 0; grp < NGRP; ++grp) {
+        BFrag nxt = cur;
+        if (grp + 1 < NGRP) nxt = load_b(grp + 1);
+#pragma unroll
+        for (int st = 0; st < GS; ++st) {
+            const int c = grp * GS + st;
+            if (c < H2K / 16) {
+                const float4 av4 = *reinterpret_cast<const float4 *>(arow + 16 * c);
+                const float a[4] = {av4.x, av4.y, av4.z, av4.w};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        if (wave + 4 * g < NG) {
+                            const float4 bv = cur.v[st][ks][g];
+                            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv.x, acc[g][0], 0, 0, 0);
+                            acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv.y, acc[g][1], 0, 0, 0);
+                            acc[g][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv.z, acc[g][2], 0, 0, 0);
+                            acc[g][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv.w, acc[g][3], 0, 0, 0);
+                        }
+                    }
+            }
+        }
+        cur = nxt;
+    }
+
+    // ---- phase C: ReLU and LayerNorm1 backward; accumulator [g][t][r] is row l4*4+r, column grp*64 + 4*l15 + t
+    float xh1[2][4][4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int c0 = (wave + 4 * g) * 64 + 4 * l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + l4 * 4 + r;
+            float4 h = make_float4(0.f, 0.f, 0.f, 0.f), x = h, gm = h;
+            const bool ok = wave + 4 * g < NG && c0 < H1 && row < n;
+            if (ok) {
+                h = *reinterpret_cast<const float4 *>(sv.h1 + (size_t)row * H1 + c0);
+                x = *reinterpret_cast<const float4 *>(sv.xh1 + (size_t)row * H1 + c0);
+                gm = *reinterpret_cast<const float4 *>(W.g1 + c0);
+            }
+            const float hh[4] = {h.x, h.y, h.z, h.w}, xx[4] = {x.x, x.y, x.z, x.w}, gg[4] = {gm.x, gm.y, gm.z, gm.w};
+            float dy[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                dy[t] = (ok && hh[t] > 0.f) ? acc[g][t][r] : 0.f;
+                xh1[g][t][r] = xx[t];
+                acc[g][t][r] = dy[t] * gg[t];                // d(x-hat)
+                s1[r] += acc[g][t][r];
+                s2[r] = fmaf(acc[g][t][r], xx[t], s2[r]);
+            }
+            if (ok) *reinterpret_cast<float4 *>(o.dy1 + (size_t)row * H1 + c0) = make_float4(dy[0], dy[1], dy[2], dy[3]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[r] = row_sum16(s1[r]); s2[r] = row_sum16(s2[r]); }
+    cross_wave_sum(red, wave, l4, l15, s1);
+    cross_wave_sum(red, wave, l4, l15, s2);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int c0 = (wave + 4 * g) * 64 + 4 * l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + l4 * 4 + r;
+            if (wave + 4 * g < NG && c0 < H1 && row < n) {
+                const float rs = sv.rstd1[row], m1 = s1[r] * (1.f / H1), m2 = s2[r] * (1.f / H1);
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = rs * (acc[g][t][r] - m1 - xh1[g][t][r] * m2);
+                *reinterpret_cast<float4 *>(o.dx1 + (size_t)row * H1 + c0) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// weight gradients.  Workgroup roles by blockIdx (one wave = one output block, K = batch in permuted k16 steps):
+//   [0, WB2)          dW2 [300,400] = dX2^T * H1: wave -> (16 rows j) x (64-column group); 19 x 7 = 133 waves
+//   [WB2, WB2+WB1)    dW1 [400,23]  = dX1^T * S : wave -> 16 rows j x 2 column tiles; 25 waves
+//   then              column sums (db2, dg2, dbe2, db1, dg1, dbe1, dw3, db3, critic: dwa, dba): a workgroup sums 64
+//                     columns, its 4 waves take a quarter of the rows each, combined through LDS
+struct Grads {
+    float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *w3, *b3, *wa, *ba;
+};
+constexpr int JT2 = (H2 + 15) / 16;                 // 19 row tiles of dW2
+constexpr int WB2 = (JT2 * NG + 3) / 4;             // 34 workgroups
+constexpr int WB1 = (H1 / 16 + 3) / 4;              // 7 workgroups (25 waves)
+constexpr int NSUM = 3 * H2 + 3 * H1 + H2 + 1 + 2 * H2;   // 3001 column-sum outputs (the last 600 critic only)
+
+__device__ __forceinline__ float colsum_term(const int q, const int b, const Saved &sv, const BwdOut &d,
+                                             const float *__restrict__ action, float *&dst, int &c, bool &valid) {
+    // q indexes the concatenation [db2 | dg2 | dbe2 | db1 | dg1 | dbe1 | dw3 | db3 | dwa | dba]
+    valid = true;
+    if (q < 3 * H2) {
+        const int which = q / H2; c = q - which * H2;
+        const size_t p = (size_t)b * H2 + c;
+        return which == 0 ? d.dx2[p] : (which == 1 ? d.dz[p] * sv.xh2[p] : d.dz[p]);
+    }
+    if (q < 3 * H2 + 3 * H1) {
+        const int qq = q - 3 * H2, which = qq / H1; c = qq - which * H1;
+        const size_t p = (size_t)b * H1 + c;
+        return which == 0 ? d.dx1[p] : (which == 1 ? d.dy1[p] * sv.xh1[p] : d.dy1[p]);
+    }
+    if (q < 3 * H2 + 3 * H1 + H2) { c = q - 3 * H2 - 3 * H1; return d.dpre[b] * sv.h2[(size_t)b * H2 + c]; }
+    if (q == 3 * H2 + 3 * H1 + H2) { c = 0; return d.dpre[b]; }
+    const int qq = q - (3 * H2 + 3 * H1 + H2 + 1), which = qq / H2; c = qq - which * H2;
+    const float dz = d.dz[(size_t)b * H2 + c];
+    return which == 0 ? dz * action[b] : dz;
+}
+
+__global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int critic, const float *__restrict__ obs,
+                                                     const float *__restrict__ action, const Saved sv,
+                                                     const BwdOut d, const Grads G) {
+    __shared__ float part[4][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int blk = blockIdx.x;
+    if (blk < WB2) {
+        const int unit = blk * 4 + wave;
+        if (unit >= JT2 * NG) return;
+        const int jt = unit / NG, grp = unit - jt * NG;
+        const int j = jt * 16 + l15, c0 = grp * 64 + 4 * l15;
+        const bool jok = j < H2, cok = c0 < H1;
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // software pipeline over groups of 4 k16 steps (64 batch rows): 16 scalars + 16 float4 per lane in flight
+        constexpr int GW = 4;
+        struct Frag { float a[GW][4]; float4 b[GW][4]; };
+        auto load_f = [&](int b0) {
+            Frag f;
+#pragma unroll
+            for (int st = 0; st < GW; ++st)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int b = b0 + 16 * st + 4 * l4 + ks;                            // permuted k order
+                    f.a[st][ks] = (b < n && jok) ? d.dx2[(size_t)b * H2 + j] : 0.f;      // A[i = j][k = b]
+                    f.b[st][ks] = (b < n && cok) ? *reinterpret_cast<const float4 *>(sv.h1 + (size_t)b * H1 + c0)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            return f;
+        };
+        Frag cur = load_f(0);
+        for (int b0 = 0; b0 < n; b0 += 16 * GW) {
+            Frag nxt = cur;
+            if (b0 + 16 * GW < n) nxt = load_f(b0 + 16 * GW);
+#pragma unroll
+            for (int st = 0; st < GW; ++st)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const float a = cur.a[st][ks];
+                    const float4 bv = cur.b[st][ks];
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv.y, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv.z, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv.w, acc[3], 0, 0, 0);
+                }
+            cur = nxt;
+        }
+        if (cok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jr = jt * 16 + l4 * 4 + r;
+                if (jr < H2)
+                    *reinterpret_cast<float4 *>(G.w2 + (size_t)jr * H1 + c0) =
+                        make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            }
+        }
+    } else if (blk < WB2 + WB1) {
+        const int jt = (blk - WB2) * 4 + wave;
+        if (jt >= H1 / 16) return;
+        const int j = jt * 16 + l15;
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 4
+        for (int b0 = 0; b0 < n; b0 += 16) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int b = b0 + 4 * l4 + ks;
+                const float a = b < n ? d.dx1[(size_t)b * H1 + j] : 0.f;
+                const float b0v = b < n ? obs[(size_t)b * IN + l15] : 0.f;                  // columns 0..15
+                const float b1v = (b < n && 16 + l15 < IN) ? obs[(size_t)b * IN + 16 + l15] : 0.f;   // 16..22
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0v, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1v, acc[1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jr = jt * 16 + l4 * 4 + r;
+            G.w1[(size_t)jr * IN + l15] = acc[0][r];
+            if (16 + l15 < IN) G.w1[(size_t)jr * IN + 16 + l15] = acc[1][r];
+        }
+    } else {
+        const int q = (blk - WB2 - WB1) * 64 + lane;
+        const int limit = critic ? NSUM : NSUM - 2 * H2;
+        float acc = 0.f;
+        float *dst = nullptr;
+        int c = 0;
+        bool valid = false;
+        if (q < limit) {
+            const int rows = (n + 3) / 4, b_lo = wave * rows, b_hi = min(n, b_lo + rows);
+            int b = b_lo;
+            for (; b + 8 <= b_hi; b += 8) {               // 8 independent loads in flight, then one add chain
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = colsum_term(q, b + u, sv, d, action, dst, c, valid);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += t[u];
+            }
+            for (; b < b_hi; ++b) acc += colsum_term(q, b, sv, d, action, dst, c, valid);
+        }
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && q < limit) {
+            const float total = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+            float *out;
+            int cc;
+            if (q < 3 * H2) { const int which = q / H2; cc = q - which * H2; out = which == 0 ? G.b2 : (which == 1 ? G.g2 : G.be2); }
+            else if (q < 3 * H2 + 3 * H1) { const int qq = q - 3 * H2, which = qq / H1; cc = qq - which * H1; out = which == 0 ? G.b1 : (which == 1 ? G.g1 : G.be1); }
+            else if (q < 3 * H2 + 3 * H1 + H2) { cc = q - 3 * H2 - 3 * H1; out = G.w3; }
+            else if (q == 3 * H2 + 3 * H1 + H2) { cc = 0; out = G.b3; }
+            else { const int qq = q - (3 * H2 + 3 * H1 + H2 + 1), which = qq / H2; cc = qq - which * H2; out = which == 0 ? G.wa : G.ba; }
+            out[cc] = total;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// torch.optim.Adam (amsgrad off, weight decay added to the gradient: networks.py:49-50,133) for every parameter
+// tensor of a net in one launch, followed by the soft target update theta' <- theta' + tau*(theta - theta')
+// (DDPG_agent.py:108-131).  step_dev holds the 1-based step count of THIS update.
+constexpr int MAXT = 12;
+struct AdamTable {
+    float *p[MAXT], *m[MAXT], *v[MAXT], *tgt[MAXT];
+    const float *g[MAXT];
+    int numel[MAXT], block_start[MAXT + 1];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void k_adam_soft(const AdamTable T, const long long *__restrict__ step_dev,
+                                                   const float lr, const float beta1, const float beta2,
+                                                   const float eps, const float weight_decay, const float tau) {
+    int ti = 0;
+    while (ti + 1 < T.count && (int)blockIdx.x >= T.block_start[ti + 1]) ++ti;
+    const int i = ((int)blockIdx.x - T.block_start[ti]) * 256 + threadIdx.x;
+    if (i >= T.numel[ti]) return;
+    const double t = (double)*step_dev;
+    const float bc1 = (float)(1.0 - pow((double)beta1, t)), bc2 = (float)(1.0 - pow((double)beta2, t));
+    float p = T.p[ti][i];
+    const float g = fmaf(weight_decay, p, T.g[ti][i]);
+    const float m = fmaf(beta1, T.m[ti][i], (1.f - beta1) * g);          // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = fmaf(beta2, T.v[ti][i], (1.f - beta2) * g * g);
+    T.m[ti][i] = m;
+    T.v[ti][i] = v;
+    const float denom = sqrtf(v) / sqrtf(bc2) + eps;
+    p -= (lr / bc1) * (m / denom);
+    T.p[ti][i] = p;
+    if (T.tgt[ti]) {
+        const float tg = T.tgt[ti][i];
+        T.tgt[ti][i] = fmaf(tau, p - tg, tg);
+    }
+}
+
+// y = r + gamma * q' * (1 - done) (DDPG_agent.py:89-93) and the learn-step counter
+__global__ void k_td_target(const int n, const float *__restrict__ r, const float *__restrict__ q_next,
+                            const uint8_t *__restrict__ done, const float gamma, float *__restrict__ y,
+                            long long *__restrict__ step_dev) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && step_dev) *step_dev += 1;
+    if (i < n) y[i] = done[i] ? r[i] : fmaf(gamma, q_next[i], r[i]);
+}
+
+Weights to_weights(const tt_mlp_weights *w) {
+    return Weights{w->w1, w->b1, w->g1, w->be1, w->w2, w->b2, w->g2, w->be2, w->w3, w->b3, w->wa, w->ba};
+}
+
+bool ok_shape(const tt_mlp_weights *w, bool critic) {
+    return w && w->in_dim == IN && w->fc1_dims == H1 && w->fc2_dims == H2 && w->w1 && w->b1 && w->g1 && w->be1 && w->w2 &&
+           w->b2 && w->g2 && w->be2 && w->w3 && w->b3 && (!critic || (w->wa && w->ba));
+}
+
+}  // namespace
+
+extern "C" {
+
+int tt_mlp_forward_save(int n, int critic, const float *obs, const float *action, const tt_mlp_weights *w, float *out,
+                        const tt_mlp_saved *saved, float *dq_da, tt_stream_t stream) {
+    if (n < 0 || !obs || !out || !ok_shape(w, critic != 0) || (critic && !action)) return TT_EINVAL;
+    if (n == 0) return TT_OK;
+    Saved sv{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (saved) {
+        if (!saved->xh1 || !saved->h1 || !saved->xh2 || !saved->h2 || !saved->rstd1 || !saved->rstd2) return TT_EINVAL;
+        sv = Saved{saved->xh1, saved->h1, saved->xh2, saved->h2, saved->rstd1, saved->rstd2};
+    }
+    const dim3 grid((n + TR - 1) / TR), block(256);
+    if (critic)
+        hipLaunchKernelGGL(k_fwd_small<true>, grid, block, 0, stream, n, obs, action, to_weights(w), out, sv, dq_da);
+    else
+        hipLaunchKernelGGL(k_fwd_small<false>, grid, block, 0, stream, n, obs, action, to_weights(w), out, sv, nullptr);
+    return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
+                    const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
+                    const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, tt_stream_t stream) {
+    if (n <= 0 || !obs || !out || !ok_shape(w, critic != 0) || !ok_shape(grads, critic != 0) || !saved || !ws ||
+        (critic && !action) || mode < 0 || mode > 2 || (mode == 0 && !d_out) || (mode == 1 && !y) || (mode == 2 && !aux))
+        return TT_EINVAL;
+    if (!saved->xh1 || !saved->h1 || !saved->xh2 || !saved->h2 || !saved->rstd1 || !saved->rstd2 || !ws->dpre || !ws->dz ||
+        !ws->dx2 || !ws->dy1 || !ws->dx1)
+        return TT_EINVAL;
+    const Saved sv{saved->xh1, saved->h1, saved->xh2, saved->h2, saved->rstd1, saved->rstd2};
+    const BwdOut o{ws->dpre, ws->dz, ws->dx2, ws->dy1, ws->dx1};
+    const dim3 grid((n + TR - 1) / TR), block(256);
+    if (critic)
+        hipLaunchKernelGGL(k_bwd_rows<true>, grid, block, 0, stream, n, mode, scale, d_out, out, y, aux,
+                           to_weights(w), sv, o);
+    else
+        hipLaunchKernelGGL(k_bwd_rows<false>, grid, block, 0, stream, n, mode, scale, d_out, out, y, aux,
+                           to_weights(w), sv, o);
+    if (hipGetLastError() != hipSuccess) return TT_EHIP;
+    const Grads G{const_cast<float *>(grads->w1), const_cast<float *>(grads->b1), const_cast<float *>(grads->g1),
+                  const_cast<float *>(grads->be1), const_cast<float *>(grads->w2), const_cast<float *>(grads->b2),
+                  const_cast<float *>(grads->g2), const_cast<float *>(grads->be2), const_cast<float *>(grads->w3),
+                  const_cast<float *>(grads->b3), const_cast<float *>(grads->wa), const_cast<float *>(grads->ba)};
+    const int sum_blocks = ((critic ? NSUM : NSUM - 2 * H2) + 63) / 64;
+    hipLaunchKernelGGL(k_bwd_weights, dim3(WB2 + WB1 + sum_blocks), block, 0, stream, n, critic, obs, action, sv, o, G);
+    return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+int tt_adam_soft_update(int count, float *const *params, const float *const *grads, float *const *exp_avg,
+                        float *const *exp_avg_sq, float *const *targets, const int32_t *numel, const int64_t *step_dev,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, float tau, tt_stream_t stream) {
+    if (count <= 0 || count > MAXT || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !step_dev) return TT_EINVAL;
+    AdamTable T{};
+    T.count = count;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] <= 0) return TT_EINVAL;
+        T.p[i] = params[i]; T.g[i] = grads[i]; T.m[i] = exp_avg[i]; T.v[i] = exp_avg_sq[i];
+        T.tgt[i] = targets ? targets[i] : nullptr;
+        T.numel[i] = numel[i];
+        T.block_start[i] = blocks;
+        blocks += (numel[i] + 255) / 256;
+    }
+    T.block_start[count] = blocks;
+    hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, stream, T, reinterpret_cast<const long long *>(step_dev), lr,
+                       beta1, beta2, eps, weight_decay, tau);
+    return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+int tt_td_target(int n, const float *reward, const float *q_next, const uint8_t *done, float gamma, float *y,
+                 int64_t *step_dev, tt_stream_t stream) {
+    if (n <= 0 || !reward || !q_next || !done || !y) return TT_EINVAL;
+    hipLaunchKernelGGL(k_td_target, dim3((n + 255) / 256), dim3(256), 0, stream, n, reward, q_next, done, gamma, y,
+                       reinterpret_cast<long long *>(step_dev));
+    return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+}  // extern "C"

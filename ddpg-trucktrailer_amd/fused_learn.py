@@ -1,0 +1,152 @@
+"""FusedLearner: Agent.learn() (DDPG/DDPG_agent.py:72-106) as ~12 hand-written HIP launches (csrc/ttlearn.hip)
+instead of ~140 autograd kernels, for the reference-shaped networks (23-400-300-1, LayerNorm) on a GPU.
+
+Same order of operations as the reference: TD target from the target nets -> critic MSE step -> actor step through
+the ALREADY UPDATED critic -> soft update of both targets.  Same optimizer arithmetic (torch.optim.Adam with the
+critic's weight decay folded into the gradient).  Parity with the torch path / the reference's fixture F5 is tested
+in tests/test_gpu_fused_learn.py."""
+import ctypes as C
+
+import torch
+
+from ddpg_trucktrailer_amd import _lib as L
+from ddpg_trucktrailer_amd import fused
+
+_ORDER = ("fc1.weight", "fc1.bias", "bn1.weight", "bn1.bias", "fc2.weight", "fc2.bias", "bn2.weight", "bn2.bias")
+_FIELDS = ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "w3", "b3", "wa", "ba")
+
+
+def _named(net):
+    d = dict(net.named_parameters())
+    head = "mu" if hasattr(net, "mu") else "q"
+    names = list(_ORDER) + [head + ".weight", head + ".bias"]
+    if hasattr(net, "action_value"):
+        names += ["action_value.weight", "action_value.bias"]
+    return [d[n] for n in names]
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class _NetState:
+    """Per-network device buffers: flat gradient (views per parameter, in tt_mlp_weights order), Adam moments."""
+
+    def __init__(self, net, target, batch, dev):
+        self.net, self.target = net, target
+        self.params = _named(net)
+        self.targets = _named(target) if target is not None else None
+        self.critic = hasattr(net, "action_value")
+        n = sum(p.numel() for p in self.params)
+        f = dict(dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, **f)
+        self.m, self.v = torch.zeros(n, **f), torch.zeros(n, **f)
+        self.grads, self.ms, self.vs, off = [], [], [], 0
+        for p in self.params:
+            k = p.numel()
+            self.grads.append(self.flat_grad[off:off + k].view_as(p))
+            self.ms.append(self.m[off:off + k]); self.vs.append(self.v[off:off + k])
+            off += k
+        self.gstruct = L.TTMlpWeights()
+        for name, g in zip(_FIELDS, self.grads):
+            setattr(self.gstruct, name, g.data_ptr())
+        self.gstruct.in_dim, self.gstruct.fc1_dims, self.gstruct.fc2_dims = 23, 400, 300
+        self.saved_t = dict(xh1=torch.empty((batch, 400), **f), h1=torch.empty((batch, 400), **f),
+                            xh2=torch.empty((batch, 300), **f), h2=torch.empty((batch, 300), **f),
+                            rstd1=torch.empty(batch, **f), rstd2=torch.empty(batch, **f))
+        self.saved = L.TTMlpSaved(**{k: v.data_ptr() for k, v in self.saved_t.items()})
+        cnt = len(self.params)
+        arr = lambda ts: (C.c_void_p * cnt)(*[t.data_ptr() for t in ts])
+        self.a_p, self.a_g, self.a_m, self.a_v = arr(self.params), arr(self.grads), arr(self.ms), arr(self.vs)
+        self.a_t = arr(self.targets) if self.targets is not None else None
+        self.a_n = (C.c_int32 * cnt)(*[p.numel() for p in self.params])
+        self.count = cnt
+
+
+class FusedLearner:
+    def __init__(self, agent, batch_size):
+        assert fused.supported(agent.actor) and fused.supported(agent.critic)
+        self.agent, self.B = agent, int(batch_size)
+        dev = self.dev = agent.actor.fc1.weight.device
+        self.lib = L.load()
+        self.critic = _NetState(agent.critic, agent.target_critic, self.B, dev)
+        self.actor = _NetState(agent.actor, agent.target_actor, self.B, dev)
+        f = dict(dtype=torch.float32, device=dev)
+        B = self.B
+        self.ws_t = dict(dpre=torch.empty(B, **f), dz=torch.empty((B, 300), **f), dx2=torch.empty((B, 300), **f),
+                         dy1=torch.empty((B, 400), **f), dx1=torch.empty((B, 400), **f))
+        self.ws = L.TTMlpBwdWs(**{k: v.data_ptr() for k, v in self.ws_t.items()})
+        self.mu_t, self.q_t, self.y, self.q, self.mu, self.q_pi, self.dq_da = (torch.empty(B, **f) for _ in range(7))
+        self.step_dev = torch.zeros((), dtype=torch.int64, device=dev)      # learn() calls done (Adam's step count)
+        self.grad_sync_critic = self.grad_sync_actor = None
+        ga, gc = agent.actor.optimizer.param_groups[0], agent.critic.optimizer.param_groups[0]
+        self.hyp_actor = (ga["lr"], ga["betas"][0], ga["betas"][1], ga["eps"], ga["weight_decay"])
+        self.hyp_critic = (gc["lr"], gc["betas"][0], gc["betas"][1], gc["eps"], gc["weight_decay"])
+
+    # -------------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _fwd(self, net, obs, action, out, saved=None, dq_da=None):
+        L.check(self.lib.tt_mlp_forward_save(self.B, 1 if action is not None else 0, _p(obs), _p(action),
+                                             C.byref(fused.weights_of(net)), _p(out), C.byref(saved) if saved else None,
+                                             _p(dq_da), self._stream()))
+
+    def _bwd(self, st, mode, scale, obs, action, out, y=None, aux=None):
+        L.check(self.lib.tt_mlp_backward(self.B, 1 if st.critic else 0, mode, float(scale), _p(obs), _p(action), None,
+                                         _p(out), _p(y), _p(aux), C.byref(fused.weights_of(st.net)), C.byref(st.saved),
+                                         C.byref(self.ws), C.byref(st.gstruct), self._stream()))
+
+    def _adam(self, st, hyp, tau):
+        lr, b1, b2, eps, wd = hyp
+        L.check(self.lib.tt_adam_soft_update(st.count, st.a_p, st.a_g, st.a_m, st.a_v, st.a_t, st.a_n, _p(self.step_dev),
+                                             lr, b1, b2, eps, wd, tau, self._stream()))
+
+    def enable_data_parallel(self, group=None):
+        """All-reduce (mean) of the flat gradient buffers at the reference's two optimizer sites."""
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+
+        def sync(flat):
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            flat.div_(world)
+        self.grad_sync_critic = lambda: sync(self.critic.flat_grad)
+        self.grad_sync_actor = lambda: sync(self.actor.flat_grad)
+
+    def learn_batch(self, states, actions, rewards, states_, done_u8):
+        """states, states_ [B,23] f32; actions [B,1] f32; rewards [B] f32; done_u8 [B] uint8 -- all contiguous."""
+        ag, B = self.agent, self.B
+        assert states.shape[0] == B and done_u8.dtype == torch.uint8
+        # targets (DDPG_agent.py:85-93)
+        self._fwd(ag.target_actor, states_, None, self.mu_t)
+        self._fwd(ag.target_critic, states_, self.mu_t, self.q_t)
+        L.check(self.lib.tt_td_target(B, _p(rewards), _p(self.q_t), _p(done_u8), float(ag.gamma), _p(self.y),
+                                      _p(self.step_dev), self._stream()))
+        # critic step (DDPG_agent.py:87, 95-98)
+        self._fwd(ag.critic, states, actions, self.q, self.critic.saved)
+        self._bwd(self.critic, 1, 2.0 / B, states, actions, self.q, y=self.y)
+        if self.grad_sync_critic is not None:
+            self.grad_sync_critic()
+        self._adam(self.critic, self.hyp_critic, ag.tau)
+        # actor step through the updated critic (DDPG_agent.py:100-104)
+        self._fwd(ag.actor, states, None, self.mu, self.actor.saved)
+        self._fwd(ag.critic, states, self.mu, self.q_pi, None, self.dq_da)
+        self._bwd(self.actor, 2, -1.0 / B, states, None, self.mu, aux=self.dq_da)
+        if self.grad_sync_actor is not None:
+            self.grad_sync_actor()
+        self._adam(self.actor, self.hyp_actor, ag.tau)
+
+    # ---- checkpoint interoperability with the torch optimizers ------------------------------------------
+    def export_to_optimizers(self):
+        step = self.step_dev.to(torch.float32).clone()
+        for st, opt in ((self.actor, self.agent.actor.optimizer), (self.critic, self.agent.critic.optimizer)):
+            for p, m, v in zip(st.params, st.ms, st.vs):
+                opt.state[p] = {"step": step.clone(), "exp_avg": m.view_as(p).clone(), "exp_avg_sq": v.view_as(p).clone()}
+
+    def import_from_optimizers(self):
+        for st, opt in ((self.actor, self.agent.actor.optimizer), (self.critic, self.agent.critic.optimizer)):
+            for p, m, v in zip(st.params, st.ms, st.vs):
+                s = opt.state.get(p)
+                if s:
+                    m.copy_(s["exp_avg"].reshape(-1)); v.copy_(s["exp_avg_sq"].reshape(-1))
+                    self.step_dev.fill_(int(float(s["step"])))

@@ -21,7 +21,7 @@ from ddpg_trucktrailer_amd.replay_buffer import TrajectoryRing
 
 class DDPGRollout:
     def __init__(self, env, batch_size=256, replay_slots=64, seed=27, alpha=1e-4, beta=1e-3, tau=1e-3, gamma=0.99,
-                 fc1_dims=400, fc2_dims=300, world_size=1, use_graph=True, agent=None):
+                 fc1_dims=400, fc2_dims=300, world_size=1, use_graph=True, agent=None, fused_learn=True):
         self.env, self.n, self.device = env, env.n_envs, env.device
         self.batch_size = batch_size
         torch.manual_seed(seed)
@@ -42,6 +42,14 @@ class DDPGRollout:
         self.seed = seed
         self.fused_act = fused.supported(self.agent.actor)      # csrc/ttnet.hip: reference-shaped 23-400-300-1 actor
         self.agent.fused_targets = self.fused_act and fused.supported(self.agent.target_critic)
+        # hand-fused learn() (csrc/ttlearn.hip) when the networks have the reference's shapes; else torch autograd
+        self.learner = None
+        if fused_learn and self.fused_act and fused.supported(self.agent.critic):
+            from ddpg_trucktrailer_amd.fused_learn import FusedLearner
+            self.learner = FusedLearner(self.agent, batch_size)
+            self.agent.fused_learner = self.learner
+            if world_size > 1:
+                self.learner.enable_data_parallel()
         self.use_graph = use_graph and world_size == 1 and self.device.type == "cuda"
         self.graph = None
         self.vector_steps = 0
@@ -65,7 +73,10 @@ class DDPGRollout:
             s, a, r, s2, d = self.ring.sample_fused(self.batch_size, seed=self.seed)
         else:
             s, a, r, s2, d = self.ring.sample(self.batch_size)
-        self.agent.learn_batch(s, a, r, s2, d)
+        if self.learner is not None:
+            self.learner.learn_batch(s, a, r, s2, self.ring._bufs[4])     # raw uint8 done flags of the sample
+        else:
+            self.agent.learn_batch(s, a, r, s2, d)
 
     def learn(self):
         if self.ring.k < 2:

@@ -216,6 +216,48 @@ int tt_ring_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const
 int tt_critic_forward(int n, const float *obs /*[n,23]*/, const float *action /*[n]*/, const tt_mlp_weights *w,
                       float *q_out, tt_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Hand-fused learn() (csrc/ttlearn.hip) for the same network shapes: Agent.learn (DDPG/DDPG_agent.py:72-106) as a
+ * dozen launches.  All buffers are caller-owned device memory, row-major f32. */
+typedef struct tt_mlp_saved {   /* what a forward keeps for its backward */
+    float *xh1, *h1;            /* [B,400] LayerNorm1-normalised fc1 output (before gamma/beta); post-ReLU activation */
+    float *xh2, *h2;            /* [B,300] same for fc2 (critic: h2 after adding action_value(a)) */
+    float *rstd1, *rstd2;       /* [B] 1/sqrt(var + eps) of the two LayerNorms */
+} tt_mlp_saved;
+
+/* Forward of the actor (critic = 0: out = tanh(mu(.))) or the critic (critic = 1: out = Q(s,a)) on a small batch,
+ * 16 rows per workgroup with the columns split over its 4 waves.  saved may be NULL (inference only); dq_da [B]
+ * (critic only, may be NULL) receives dQ/da. */
+int tt_mlp_forward_save(int n, int critic, const float *obs, const float *action, const tt_mlp_weights *w, float *out,
+                        const tt_mlp_saved *saved, float *dq_da, tt_stream_t stream);
+
+/* Backward of one net on the batch (autograd of networks.py:55-68 / 138-147): workspace ws holds the per-row
+ * gradients (dpre [B], dz, dx2 [B,300], dy1, dx1 [B,400]); grads has the layout of tt_mlp_weights and receives
+ * d(loss)/d(parameter) for every parameter (overwritten, not accumulated).
+ *   mode 0: d_out [B] = d(loss)/d(out) given;
+ *   mode 1: d(loss)/d(out) = scale*(out - y)   (critic: loss = mse_loss(y, q), scale = 2/B; DDPG_agent.py:96-97);
+ *   mode 2: d(loss)/d(out) = scale*aux         (actor: loss = -mean Q(s, mu(s)), aux = dQ/da from
+ *                                               tt_mlp_forward_save on the critic, scale = -1/B; DDPG_agent.py:101-103). */
+typedef struct tt_mlp_bwd_ws {
+    float *dpre, *dz, *dx2, *dy1, *dx1;
+} tt_mlp_bwd_ws;
+int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
+                    const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
+                    const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, tt_stream_t stream);
+
+/* optimizer.step() of torch.optim.Adam (weight decay folded into the gradient; networks.py:49-50,133) for `count`
+ * (<= 12) parameter tensors in one launch, then the soft update of the matching target tensors
+ * (Agent.update_network_parameters, DDPG_agent.py:108-131; targets NULL = none).  The arrays are HOST arrays of device
+ * pointers; *step_dev (device) is the 1-based count of this step. */
+int tt_adam_soft_update(int count, float *const *params, const float *const *grads, float *const *exp_avg,
+                        float *const *exp_avg_sq, float *const *targets, const int32_t *numel, const int64_t *step_dev,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, float tau, tt_stream_t stream);
+
+/* target = rewards + gamma * critic_value_ with critic_value_[done] = 0 (DDPG_agent.py:89-93); also advances the
+ * learn-step counter *step_dev (may be NULL) that tt_adam_soft_update reads. */
+int tt_td_target(int n, const float *reward, const float *q_next, const uint8_t *done, float gamma, float *y,
+                 int64_t *step_dev, tt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,123 @@
+"""GPU (-m gpu): the hand-fused learn() kernels (csrc/ttlearn.hip) against torch autograd on the same nets and
+against fixture F5 (the reference's own learn()).  Tolerances as in tests/test_learner.py."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, seed=0, B=256):
+    import torch
+    from test_gpu_fused_net import _nets
+    actor, critic = _nets(dev, seed)
+    g = torch.Generator(device=dev).manual_seed(seed + 1)
+    s = torch.rand((B, 23), device=dev, generator=g) * 2 - 1
+    a = torch.rand((B, 1), device=dev, generator=g) * 2.4 - 1.2
+    return actor, critic, s, a, g
+
+
+@pytest.mark.parametrize("B", [256, 100, 16])
+def test_forward_save_and_backward_match_autograd(gpu_device, B):
+    import ctypes as C
+    import torch
+    from ddpg_trucktrailer_amd import _lib as L, fused
+    from ddpg_trucktrailer_amd.fused_learn import _NetState, _p
+    actor, critic, s, a, g = _setup(gpu_device, seed=B, B=B)
+    lib = L.load()
+    f = dict(dtype=torch.float32, device=gpu_device)
+    ws_t = dict(dpre=torch.empty(B, **f), dz=torch.empty((B, 300), **f), dx2=torch.empty((B, 300), **f),
+                dy1=torch.empty((B, 400), **f), dx1=torch.empty((B, 400), **f))
+    ws = L.TTMlpBwdWs(**{k: v.data_ptr() for k, v in ws_t.items()})
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for net, act in ((actor, None), (critic, a)):
+        st = _NetState(net, None, B, gpu_device)
+        out = torch.empty(B, **f)
+        dq_da = torch.empty(B, **f) if act is not None else None
+        L.check(lib.tt_mlp_forward_save(B, 1 if act is not None else 0, _p(s), _p(act), C.byref(fused.weights_of(net)), _p(out),
+                                        C.byref(st.saved), _p(dq_da), stream))
+        a_req = act.clone().requires_grad_(True) if act is not None else None
+        ref = net(s) if act is None else net(s, a_req)
+        assert (out.view(-1, 1) - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+        # saved activations = what autograd would keep
+        x1 = net.fc1(s); h1 = torch.relu(net.bn1(x1))
+        xh1 = (x1 - x1.mean(1, keepdim=True)) * torch.rsqrt(x1.var(1, unbiased=False, keepdim=True) + 1e-5)
+        assert (st.saved_t["xh1"] - xh1).abs().max().item() <= 2e-5 and (st.saved_t["h1"] - h1).abs().max().item() <= 2e-5
+        d_out = torch.randn(B, generator=g, **f)
+        net.zero_grad(set_to_none=True)
+        ref.backward(d_out.view(-1, 1))
+        if act is not None:
+            assert (dq_da - torch.autograd.grad(net(s, a_req).sum(), a_req)[0].view(-1)).abs().max().item() <= 2e-5
+        L.check(lib.tt_mlp_backward(B, 1 if act is not None else 0, 0, 1.0, _p(s), _p(act), _p(d_out), _p(out), None, None,
+                                    C.byref(fused.weights_of(net)), C.byref(st.saved), C.byref(ws), C.byref(st.gstruct), stream))
+        for p, gk in zip(st.params, st.grads):
+            scale = max(1e-3, p.grad.abs().max().item())
+            assert (gk - p.grad).abs().max().item() <= 3e-5 * scale + 1e-6, (tuple(p.shape), (gk - p.grad).abs().max().item(), scale)
+
+
+def _agent(dev, z, capturable=False):
+    from ddpg_trucktrailer_amd.agent import Agent
+    from test_learner import _load_init
+    a = Agent(alpha=1e-4, beta=1e-3, input_dims=(23,), tau=1e-3, n_actions=1, batch_size=256, device=dev, replay=False,
+              capturable=capturable)
+    _load_init(a, z)
+    return a
+
+
+def test_fused_learn_matches_reference_fixture_and_torch_path(gpu_device):
+    import torch
+    from conftest import GOLDEN
+    from ddpg_trucktrailer_amd.fused_learn import FusedLearner
+    from test_learner import _batch, _check_snapshot
+    z = np.load(os.path.join(GOLDEN, "f5_learner.npz"), allow_pickle=False)
+    fused_agent, torch_agent = _agent(gpu_device, z), _agent(gpu_device, z)
+    s, a, r, s2, d = _batch(z, gpu_device)
+    fl = FusedLearner(fused_agent, 256)
+    d8 = d.to(torch.uint8)
+    fl.learn_batch(s, a, r, s2, d8)
+    torch_agent.learn_batch(s, a, r, s2, d)
+    _check_snapshot(fused_agent, z, "after1", 1e-5)                 # vs the REFERENCE's learn()
+    assert (fl.y - torch.tensor(z["target_y"], device=gpu_device)).abs().max().item() <= 1e-5 * np.abs(z["target_y"]).max()
+    for _ in range(2):
+        fl.learn_batch(s, a, r, s2, d8)
+        torch_agent.learn_batch(s, a, r, s2, d)
+    _check_snapshot(fused_agent, z, "after3", 4e-5)
+    for name in ("actor", "critic", "target_actor", "target_critic"):
+        for (k, x), y in zip(getattr(fused_agent, name).state_dict().items(), getattr(torch_agent, name).state_dict().values()):
+            assert (x - y).abs().max().item() <= 4e-5 * max(1e-1, y.abs().max().item()) + 1e-6, (name, k)
+    assert int(fl.step_dev.item()) == 3
+    # Adam state round trip with the torch optimizers (checkpoint interoperability)
+    fl.export_to_optimizers()
+    st = fused_agent.critic.optimizer.state[fused_agent.critic.fc2.weight]
+    ref = torch_agent.critic.optimizer.state[torch_agent.critic.fc2.weight]
+    assert float(st["step"]) == 3 and torch.allclose(st["exp_avg"], ref["exp_avg"], rtol=1e-3, atol=1e-7)
+    fl2 = FusedLearner(fused_agent, 256)
+    fl2.import_from_optimizers()
+    assert int(fl2.step_dev.item()) == 3 and torch.equal(fl2.critic.m, fl.critic.m)
+
+
+def test_fused_learn_in_hipgraph(gpu_device):
+    """Captured once, replayed: every replay advances the step counter and keeps matching the eager fused path."""
+    import torch
+    from conftest import GOLDEN
+    from ddpg_trucktrailer_amd.fused_learn import FusedLearner
+    from test_learner import _batch
+    z = np.load(os.path.join(GOLDEN, "f5_learner.npz"), allow_pickle=False)
+    eager_agent, graph_agent = _agent(gpu_device, z), _agent(gpu_device, z)
+    s, a, r, s2, d = _batch(z, gpu_device)
+    d8 = d.to(torch.uint8)
+    fe, fg = FusedLearner(eager_agent, 256), FusedLearner(graph_agent, 256)
+    fe.learn_batch(s, a, r, s2, d8); fg.learn_batch(s, a, r, s2, d8)          # warm-up (also sets kernel attributes)
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        fg.learn_batch(s, a, r, s2, d8)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        g.replay(); fe.learn_batch(s, a, r, s2, d8)
+    torch.cuda.synchronize()
+    assert int(fg.step_dev.item()) == int(fe.step_dev.item()) == 4
+    for name in ("actor", "critic", "target_actor", "target_critic"):
+        for x, y in zip(getattr(eager_agent, name).state_dict().values(), getattr(graph_agent, name).state_dict().values()):
+            assert torch.equal(x, y), name
