@@ -129,11 +129,18 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path is a HIP kernel)"
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") over xGMI is the product path; TT_DIST_BACKEND=gloo lets the N>1 code path be rehearsed with
+        # several ranks on ONE GPU (RCCL refuses two ranks per device)
+        backend = os.environ.get("TT_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
 

@@ -68,3 +68,57 @@ def test_two_rank_gradient_allreduce_matches_reference_full_batch(tmp_path):
                 got = got.reshape(-1)[::stride]
             ref = z[f"after3/{name}/{k}"]
             assert np.abs(got - ref).max() <= 4e-5 * max(1e-1, np.abs(ref).max()) + 1e-6, (name, k)
+
+
+def _gpu_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # two ranks on ONE GPU: RCCL would refuse that
+    dev = torch.device("cuda:0")
+    from ddpg_trucktrailer_amd.agent import Agent
+    from ddpg_trucktrailer_amd.fused_learn import FusedLearner
+    from test_learner import _load_init
+    z = np.load(F5, allow_pickle=False)
+    torch.manual_seed(100 + rank)
+    agent = Agent(alpha=1e-4, beta=1e-3, input_dims=(23,), tau=1e-3, n_actions=1, batch_size=128, device=dev, replay=False)
+    if rank == 0:
+        _load_init(agent, z)
+    agent.enable_data_parallel()                 # broadcast of rank 0's weights
+    agent.update_network_parameters(tau=1)
+    fl = FusedLearner(agent, 128)
+    fl.enable_data_parallel()
+    half = slice(rank * 128, (rank + 1) * 128)
+    f = lambda k: torch.tensor(z[k][half], dtype=torch.float, device=dev)
+    d8 = torch.tensor(z["batch_dones"][half].astype(np.uint8), device=dev)
+    for _ in range(3):
+        fl.learn_batch(f("batch_states"), f("batch_actions"), f("batch_rewards"), f("batch_states_"), d8)
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().reshape(-1) for net in agent._nets() for p in net.parameters()]).cpu()
+    torch.save(flat, os.path.join(out_dir, f"rank{rank}.pt"))
+    if rank == 0:
+        torch.save({n: {k: v.cpu() for k, v in getattr(agent, n).state_dict().items()}
+                    for n in ("actor", "critic", "target_actor", "target_critic")}, os.path.join(out_dir, "state.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_fused_learner_matches_reference_full_batch(tmp_path, gpu_device):
+    """The hand-fused learn() with the flat-gradient all-reduce: two ranks x half batches == the reference's
+    full-batch learn() (fixture F5); ranks bit-identical."""
+    port = _free_port()
+    mp.start_processes(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    a = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    b = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    assert torch.equal(a, b), "ranks diverged"
+    z = np.load(F5, allow_pickle=False)
+    state = torch.load(tmp_path / "state.pt", weights_only=True)
+    stride = int(z["sample_stride"])
+    for name, sd in state.items():
+        for k, v in sd.items():
+            got = v.numpy()
+            if k == "fc2.weight":
+                got = got.reshape(-1)[::stride]
+            ref = z[f"after3/{name}/{k}"]
+            assert np.abs(got - ref).max() <= 4e-5 * max(1e-1, np.abs(ref).max()) + 1e-6, (name, k)
