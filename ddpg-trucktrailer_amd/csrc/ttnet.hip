@@ -19,6 +19,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "ttenv.h"
 
@@ -267,6 +268,390 @@ __global__ __launch_bounds__(256, 1) void k_mlp_forward(const int n, const float
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// v2 of the forward: no LDS weight ring and no barrier inside the K loop.  fc1 and fc2 fragments are read straight
+// from L2 (they are shared by every workgroup, 37 KB + 480 KB), fc2 with the permuted-k trick: in one "k16 step"
+// lane l contributes k = k0 + 4*(l>>4) + ks to MFMA ks, so its four B values are one float4 of a weight row and its
+// four A values one ds_read_b128 of the activation tile.  The loads of the NEXT two k16 steps (40 float4 per lane)
+// are in flight while the 160 MFMAs of the current two issue.
+constexpr int HS2 = 404;     // activation tile row stride: 16-byte rows; 404 mod 64 = 20 spreads 16 rows over all banks
+constexpr int V2_LDS_BYTES = (BM * HS2 + H1 * IN + 3 * H1 + 6 * H2) * 4;      // 103,424 + 36,800 + 4,800 + 7,200 = 152,224 B
+
+template <bool CRITIC>
+__global__ __launch_bounds__(256, 1) void k_mlp_forward_v2(const int n, const float *__restrict__ obs,
+                                                           const float *__restrict__ action, const Weights W,
+                                                           float *__restrict__ out, const ActArgs act) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *h1_s = lds;                       // [64][404]; each wave only touches its own 16 rows
+    float *w1_s = h1_s + BM * HS2;           // fc1 weights, raw [400][23] (stride 23 is odd: fragment reads spread over banks)
+    float *p1_s = w1_s + H1 * IN;            // b1 | g1 | be1        [3][400]
+    float *p2_s = p1_s + 3 * H1;             // b2 | g2 | be2 | w3 (| wa | ba)   [6][300]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int row0 = blockIdx.x * BM, wrow0 = row0 + wave * WROWS;
+
+    // ---- one cooperative, fully coalesced copy of everything small that every wave needs: a single L2 round trip
+    // instead of ~25 dependent ones (the fragment loads of layer 1 would otherwise each wait on L2)
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(W.w1);           // 9200 floats = 2300 float4
+        float4 *dst = reinterpret_cast<float4 *>(w1_s);
+        for (int i = tid; i < H1 * IN / 4; i += 256) dst[i] = src[i];
+        for (int i = tid; i < H1; i += 256) { p1_s[i] = W.b1[i]; p1_s[H1 + i] = W.g1[i]; p1_s[2 * H1 + i] = W.be1[i]; }
+        for (int i = tid; i < H2; i += 256) {
+            p2_s[i] = W.b2[i]; p2_s[H2 + i] = W.g2[i]; p2_s[2 * H2 + i] = W.be2[i]; p2_s[3 * H2 + i] = W.w3[i];
+            if (CRITIC) { p2_s[4 * H2 + i] = W.wa[i]; p2_s[5 * H2 + i] = W.ba[i]; }
+        }
+    }
+    // ---- layer 1 (K = 23)
+    f32x4 acc1[NT1];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        float a[INP / 4];
+#pragma unroll
+        for (int ks = 0; ks < INP / 4; ++ks) {
+            const int k = ks * 4 + l4;
+            a[ks] = (k < IN && wrow0 + l15 < n) ? obs[(size_t)(wrow0 + l15) * IN + k] : 0.f;
+        }
+        __syncthreads();                     // staged weights visible
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            float b[INP / 4];
+#pragma unroll
+            for (int ks = 0; ks < INP / 4; ++ks) {
+                const int k = ks * 4 + l4;
+                b[ks] = k < IN ? w1_s[(t * 16 + l15) * IN + k] : 0.f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < INP / 4; ++ks) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b[ks], acc1[t], 0, 0, 0);
+        }
+    }
+    {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            const float bias = p1_s[t * 16 + l15];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc1[t][r] += bias; s[r] += acc1[t][r]; }
+        }
+        float mean[4], rstd[4], ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mean[r] = row_sum16(s[r]) * (1.f / H1);
+#pragma unroll
+        for (int t = 0; t < NT1; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = acc1[t][r] - mean[r]; ss[r] = fmaf(d, d, ss[r]); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rstd[r] = rsqrtf(row_sum16(ss[r]) * (1.f / H1) + 1e-5f);
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            const int col = t * 16 + l15;
+            const float g = p1_s[H1 + col], be = p1_s[2 * H1 + col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                h1_s[(wave * WROWS + l4 * 4 + r) * HS2 + col] = fmaxf(fmaf((acc1[t][r] - mean[r]) * rstd[r], g, be), 0.f);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS writes have landed (rows are wave-private)
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- layer 2
+    f32x4 acc2[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef TT_DBG_SHORT_K
+    constexpr int SS = 2, NSS = 1;     // timing experiment only: 2 of the 25 k16 steps
+#else
+    constexpr int SS = 2, NSS = (H1 / 16 + SS - 1) / SS;          // 25 k16 steps -> 13 super-steps (the last holds 1)
+#endif
+    struct BFrag { float4 v[SS][NT2]; };
+    const float *wbase = W.w2 + (size_t)l15 * H1 + 4 * l4;        // + t*16*H1 per tile
+    auto load_b = [&](int ss) {
+        BFrag f;
+#pragma unroll
+        for (int st = 0; st < SS; ++st) {
+            const int c = ss * SS + st;
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) {
+                const bool real = c < H1 / 16 && t * 16 + l15 < H2;
+                f.v[st][t] = real ? *reinterpret_cast<const float4 *>(wbase + (size_t)t * 16 * H1 + 16 * c)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        return f;
+    };
+    const float *arow = h1_s + (wave * WROWS + l15) * HS2 + 4 * l4;
+    BFrag cur = load_b(0);
+    for (int ss = 0; ss < NSS; ++ss) {
+        BFrag nxt = cur;
+        if (ss + 1 < NSS) nxt = load_b(ss + 1);
+#pragma unroll
+        for (int st = 0; st < SS; ++st) {
+            const int c = ss * SS + st;
+            if (c < H1 / 16) {
+                const float4 av = *reinterpret_cast<const float4 *>(arow + 16 * c);
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, cur.v[st][t].x, acc2[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, cur.v[st][t].y, acc2[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, cur.v[st][t].z, acc2[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, cur.v[st][t].w, acc2[t], 0, 0, 0);
+            }
+        }
+        cur = nxt;
+    }
+
+    // ---- epilogue (same as v1)
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+        const int col = t * 16 + l15;
+        const bool real = col < H2;
+        const float bias = real ? p2_s[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc2[t][r] = real ? acc2[t][r] + bias : 0.f; s[r] += acc2[t][r]; }
+    }
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mean[r] = row_sum16(s[r]) * (1.f / H2);
+    float ss2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+        const bool real = t * 16 + l15 < H2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = real ? acc2[t][r] - mean[r] : 0.f; ss2[r] = fmaf(d, d, ss2[r]); }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rstd[r] = rsqrtf(row_sum16(ss2[r]) * (1.f / H2) + 1e-5f);
+    float av[4] = {0.f, 0.f, 0.f, 0.f};
+    if (CRITIC) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wrow0 + l4 * 4 + r;
+            av[r] = row < n ? action[row] : 0.f;
+        }
+    }
+    float dot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+        const int col = t * 16 + l15;
+        if (col < H2) {
+            const float g = p2_s[H2 + col], be = p2_s[2 * H2 + col], w3 = p2_s[3 * H2 + col];
+            float wa = 0.f, ba = 0.f;
+            if (CRITIC) { wa = p2_s[4 * H2 + col]; ba = p2_s[5 * H2 + col]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float y = fmaf((acc2[t][r] - mean[r]) * rstd[r], g, be);
+                if (CRITIC) y += fmaf(av[r], wa, ba);
+                dot[r] = fmaf(fmaxf(y, 0.f), w3, dot[r]);
+            }
+        }
+    }
+    const float b3 = W.b3[0];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float v = row_sum16(dot[r]) + b3;
+        const int row = wrow0 + l4 * 4 + r;
+        if (l15 == 0 && row < n) {
+            if (CRITIC) {
+                out[row] = v;
+            } else {
+                const float mu = tanhf(v);
+                if (out) out[row] = mu;
+                if (act.ou) {
+                    float x = act.ou[row];
+                    if (act.done_prev && act.done_prev[row]) x = 0.f;
+                    const unsigned long long st = act.step + (act.step_dev ? (unsigned long long)*act.step_dev : 0ull);
+                    uint32_t rnd[4];
+                    philox4x32((uint32_t)row, (uint32_t)st, (uint32_t)(st >> 32), 0x0A5Eu, (uint32_t)act.seed,
+                               (uint32_t)(act.seed >> 32), rnd);
+                    const float u1 = ((float)(rnd[0] >> 8) + 0.5f) * (1.f / 16777216.f);
+                    const float u2 = ((float)(rnd[1] >> 8) + 0.5f) * (1.f / 16777216.f);
+                    const float nrm = sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+                    x = fmaf(x, act.decay, act.scale * nrm);
+                    act.ou[row] = x;
+                    const float a = mu + x;
+                    act.act_raw[row] = a;
+                    act.act_scaled[row] = fminf(fmaxf(a, -1.f), 1.f) * act.high;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// v3: as v2 but 32 rows (2 waves) per workgroup and at most 256 registers per lane, so that three workgroups fit on
+// a CU (52 KB of LDS each): one wave's LayerNorm / epilogue / load latency hides behind another wave's MFMAs.
+constexpr int BM3 = 32;
+constexpr int V3_LDS_BYTES = BM3 * HS2 * 4;     // 51,712 B
+
+template <bool CRITIC>
+__global__ __launch_bounds__(128, 2) void k_mlp_forward_v3(const int n, const float *__restrict__ obs,
+                                                           const float *__restrict__ action, const Weights W,
+                                                           float *__restrict__ out, const ActArgs act) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *h1_s = lds;                       // [32][404]; each wave only touches its own 16 rows
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int row0 = blockIdx.x * BM3, wrow0 = row0 + wave * WROWS;
+
+    // ---- layer 1 (K = 23), operands from global
+    f32x4 acc1[NT1];
+#pragma unroll
+    for (int t = 0; t < NT1; ++t) acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        float a[INP / 4];
+#pragma unroll
+        for (int ks = 0; ks < INP / 4; ++ks) {
+            const int k = ks * 4 + l4;
+            a[ks] = (k < IN && wrow0 + l15 < n) ? obs[(size_t)(wrow0 + l15) * IN + k] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            float b[INP / 4];
+#pragma unroll
+            for (int ks = 0; ks < INP / 4; ++ks) {
+                const int k = ks * 4 + l4;
+                b[ks] = k < IN ? W.w1[(t * 16 + l15) * IN + k] : 0.f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < INP / 4; ++ks) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b[ks], acc1[t], 0, 0, 0);
+        }
+    }
+    {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            const float bias = W.b1[t * 16 + l15];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc1[t][r] += bias; s[r] += acc1[t][r]; }
+        }
+        float mean[4], rstd[4], ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mean[r] = row_sum16(s[r]) * (1.f / H1);
+#pragma unroll
+        for (int t = 0; t < NT1; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = acc1[t][r] - mean[r]; ss[r] = fmaf(d, d, ss[r]); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rstd[r] = rsqrtf(row_sum16(ss[r]) * (1.f / H1) + 1e-5f);
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            const int col = t * 16 + l15;
+            const float g = W.g1[col], be = W.be1[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                h1_s[(wave * WROWS + l4 * 4 + r) * HS2 + col] = fmaxf(fmaf((acc1[t][r] - mean[r]) * rstd[r], g, be), 0.f);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS writes have landed (rows are wave-private)
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- layer 2
+    f32x4 acc2[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // No explicit prefetch here: two to three workgroups share a CU (52 KB of LDS each), so while this wave waits
+    // for its 20 weight rows the other wave of the SIMD issues MFMAs.
+    const float *wbase = W.w2 + (size_t)l15 * H1 + 4 * l4;        // + t*16*H1 per tile
+    const float *arow = h1_s + (wave * WROWS + l15) * HS2 + 4 * l4;
+    for (int c = 0; c < H1 / 16; ++c) {
+        float4 bv[NT2];
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+            bv[t] = t * 16 + l15 < H2 ? *reinterpret_cast<const float4 *>(wbase + (size_t)t * 16 * H1 + 16 * c)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 av = *reinterpret_cast<const float4 *>(arow + 16 * c);
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[t].x, acc2[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[t].y, acc2[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[t].z, acc2[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[t].w, acc2[t], 0, 0, 0);
+    }
+
+    // ---- epilogue (same as v1)
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+        const int col = t * 16 + l15;
+        const bool real = col < H2;
+        const float bias = real ? W.b2[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc2[t][r] = real ? acc2[t][r] + bias : 0.f; s[r] += acc2[t][r]; }
+    }
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mean[r] = row_sum16(s[r]) * (1.f / H2);
+    float ss2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+        const bool real = t * 16 + l15 < H2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = real ? acc2[t][r] - mean[r] : 0.f; ss2[r] = fmaf(d, d, ss2[r]); }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rstd[r] = rsqrtf(row_sum16(ss2[r]) * (1.f / H2) + 1e-5f);
+    float av[4] = {0.f, 0.f, 0.f, 0.f};
+    if (CRITIC) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wrow0 + l4 * 4 + r;
+            av[r] = row < n ? action[row] : 0.f;
+        }
+    }
+    float dot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+        const int col = t * 16 + l15;
+        if (col < H2) {
+            const float g = W.g2[col], be = W.be2[col], w3 = W.w3[col];
+            float wa = 0.f, ba = 0.f;
+            if (CRITIC) { wa = W.wa[col]; ba = W.ba[col]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float y = fmaf((acc2[t][r] - mean[r]) * rstd[r], g, be);
+                if (CRITIC) y += fmaf(av[r], wa, ba);
+                dot[r] = fmaf(fmaxf(y, 0.f), w3, dot[r]);
+            }
+        }
+    }
+    const float b3 = W.b3[0];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float v = row_sum16(dot[r]) + b3;
+        const int row = wrow0 + l4 * 4 + r;
+        if (l15 == 0 && row < n) {
+            if (CRITIC) {
+                out[row] = v;
+            } else {
+                const float mu = tanhf(v);
+                if (out) out[row] = mu;
+                if (act.ou) {
+                    float x = act.ou[row];
+                    if (act.done_prev && act.done_prev[row]) x = 0.f;
+                    const unsigned long long st = act.step + (act.step_dev ? (unsigned long long)*act.step_dev : 0ull);
+                    uint32_t rnd[4];
+                    philox4x32((uint32_t)row, (uint32_t)st, (uint32_t)(st >> 32), 0x0A5Eu, (uint32_t)act.seed,
+                               (uint32_t)(act.seed >> 32), rnd);
+                    const float u1 = ((float)(rnd[0] >> 8) + 0.5f) * (1.f / 16777216.f);
+                    const float u2 = ((float)(rnd[1] >> 8) + 0.5f) * (1.f / 16777216.f);
+                    const float nrm = sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+                    x = fmaf(x, act.decay, act.scale * nrm);
+                    act.ou[row] = x;
+                    const float a = mu + x;
+                    act.act_raw[row] = a;
+                    act.act_scaled[row] = fminf(fmaxf(a, -1.f), 1.f) * act.high;
+                }
+            }
+        }
+    }
+}
+
 // Uniform sampling WITH replacement from the trajectory ring (replay_buffer.py:23-34 draws np.random.choice(max_mem,
 // batch)): one workgroup per sampled transition gathers s, a, r, s', done into the batch buffers.  The ring's step
 // counter is read from device memory so that a captured hipGraph of learn() samples fresh indices every replay
@@ -312,9 +697,42 @@ Weights to_weights(const tt_mlp_weights *w) {
     return Weights{w->w1, w->b1, w->g1, w->be1, w->w2, w->b2, w->g2, w->be2, w->w3, w->b3, w->wa, w->ba};
 }
 
+int mlp_version() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("TT_MLP_VERSION");       // A/B switch for measurements; 2 = direct-from-L2 weights
+        v = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 2;
+    }
+    return v;
+}
+
 template <bool CRITIC>
 int launch(int n, const float *obs, const float *action, const tt_mlp_weights *w, float *out, const ActArgs &act,
            hipStream_t stream) {
+    if (mlp_version() == 3) {
+        static bool attr3 = false;
+        if (!attr3) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_forward_v3<CRITIC>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS_BYTES) != hipSuccess)
+                return TT_EHIP;
+            attr3 = true;
+        }
+        hipLaunchKernelGGL((k_mlp_forward_v3<CRITIC>), dim3((n + BM3 - 1) / BM3), dim3(128), V3_LDS_BYTES, stream, n, obs,
+                           action, to_weights(w), out, act);
+        return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+    }
+    if (mlp_version() == 2) {
+        static bool attr2 = false;
+        if (!attr2) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_forward_v2<CRITIC>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES) != hipSuccess)
+                return TT_EHIP;
+            attr2 = true;
+        }
+        hipLaunchKernelGGL((k_mlp_forward_v2<CRITIC>), dim3((n + BM - 1) / BM), dim3(256), V2_LDS_BYTES, stream, n, obs,
+                           action, to_weights(w), out, act);
+        return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_forward<CRITIC>),

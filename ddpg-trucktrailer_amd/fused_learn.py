@@ -78,6 +78,7 @@ class FusedLearner:
         self.ws = L.TTMlpBwdWs(**{k: v.data_ptr() for k, v in self.ws_t.items()})
         self.mu_t, self.q_t, self.y, self.q, self.mu, self.q_pi, self.dq_da = (torch.empty(B, **f) for _ in range(7))
         self.step_dev = torch.zeros((), dtype=torch.int64, device=dev)      # learn() calls done (Adam's step count)
+        self.side = torch.cuda.Stream(device=dev)      # the two forwards that do not depend on the TD target run here
         self.grad_sync_critic = self.grad_sync_actor = None
         ga, gc = agent.actor.optimizer.param_groups[0], agent.critic.optimizer.param_groups[0]
         self.hyp_actor = (ga["lr"], ga["betas"][0], ga["betas"][1], ga["eps"], ga["weight_decay"])
@@ -117,19 +118,25 @@ class FusedLearner:
         """states, states_ [B,23] f32; actions [B,1] f32; rewards [B] f32; done_u8 [B] uint8 -- all contiguous."""
         ag, B = self.agent, self.B
         assert states.shape[0] == B and done_u8.dtype == torch.uint8
+        # Q(s,a) (DDPG_agent.py:87) and mu(s) (:101) need neither the TD target nor the critic update, so they run
+        # on a side stream next to the target-network passes (each of these kernels fills only 16 of the 256 CUs)
+        main = torch.cuda.current_stream(self.dev)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            self._fwd(ag.critic, states, actions, self.q, self.critic.saved)
+            self._fwd(ag.actor, states, None, self.mu, self.actor.saved)
         # targets (DDPG_agent.py:85-93)
         self._fwd(ag.target_actor, states_, None, self.mu_t)
         self._fwd(ag.target_critic, states_, self.mu_t, self.q_t)
         L.check(self.lib.tt_td_target(B, _p(rewards), _p(self.q_t), _p(done_u8), float(ag.gamma), _p(self.y),
                                       _p(self.step_dev), self._stream()))
-        # critic step (DDPG_agent.py:87, 95-98)
-        self._fwd(ag.critic, states, actions, self.q, self.critic.saved)
+        main.wait_stream(self.side)
+        # critic step (DDPG_agent.py:95-98)
         self._bwd(self.critic, 1, 2.0 / B, states, actions, self.q, y=self.y)
         if self.grad_sync_critic is not None:
             self.grad_sync_critic()
         self._adam(self.critic, self.hyp_critic, ag.tau)
-        # actor step through the updated critic (DDPG_agent.py:100-104)
-        self._fwd(ag.actor, states, None, self.mu, self.actor.saved)
+        # actor step through the UPDATED critic (DDPG_agent.py:100-104)
         self._fwd(ag.critic, states, self.mu, self.q_pi, None, self.dq_da)
         self._bwd(self.actor, 2, -1.0 / B, states, None, self.mu, aux=self.dq_da)
         if self.grad_sync_actor is not None:
