@@ -23,18 +23,31 @@ constexpr int IN = 23, INP = 24;
 constexpr int H1 = 400, H2 = 300, H2P = 320, H2K = 304;   // H2K: fc2 outputs rounded up to whole k16 steps
 constexpr int NT1 = H1 / 16, NT2 = H2P / 16;
 constexpr int TR = 16;                    // rows per workgroup
+constexpr int NW = 8;                     // waves per workgroup: two per SIMD, so one wave's load latency hides behind
+                                          // the other's MFMAs (hipcc does not keep a deep software prefetch in place)
 constexpr int HS1 = 404;                  // LDS row stride of the 16 x 400 activation tile: 16-byte rows, and 404 mod 64 = 20
                                           // spreads the 16 rows of a ds_read_b128 fragment over all 64 banks
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+#ifdef TT_STAMPS   // diagnostic build only: wall-clock stamps (100 MHz) of workgroup 0 / wave 0 at phase boundaries
+__device__ unsigned long long g_stamps[32];
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_stamps[i] = wall_clock64(); g_stamps[16 + i] = clock64(); } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+// __restrict__ on the members: none of these buffers alias, and without it every store (saved activations,
+// gradients) pins the loads that follow it in program order
 struct Weights {
-    const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *w3, *b3, *wa, *ba;
+    const float *__restrict__ w1, *__restrict__ b1, *__restrict__ g1, *__restrict__ be1, *__restrict__ w2,
+        *__restrict__ b2, *__restrict__ g2, *__restrict__ be2, *__restrict__ w3, *__restrict__ b3, *__restrict__ wa,
+        *__restrict__ ba;
 };
 struct Saved {          // forward activations kept for the backward (all [B, .] row-major f32)
-    float *xh1, *h1;    // [B,400] normalised fc1 output (before gamma/beta), post-ReLU activation
-    float *xh2, *h2;    // [B,300] normalised fc2 output, post-ReLU activation (critic: after + action_value)
-    float *rstd1, *rstd2;   // [B]
+    float *__restrict__ xh1, *__restrict__ h1;    // [B,400] normalised fc1 output (before gamma/beta), post-ReLU activation
+    float *__restrict__ xh2, *__restrict__ h2;    // [B,300] normalised fc2 output, post-ReLU (critic: after + action_value)
+    float *__restrict__ rstd1, *__restrict__ rstd2;   // [B]
 };
 
 __device__ __forceinline__ float row_sum16(float v) {
@@ -46,7 +59,7 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 
 // combine a per-wave, per-row partial (valid in every lane of the 16-lane group of that row) across the 4 waves.
-// red: [4 waves][16 rows].  Two barriers; every lane returns the total of ITS four rows (r = 0..3).
+// red: [NW waves][16 rows].  Two barriers; every lane returns the total of ITS four rows (r = 0..3).
 __device__ __forceinline__ void cross_wave_sum(float *red, int wave, int l4, int l15, float (&v)[4]) {
     __syncthreads();                       // previous use of `red` is over
     if (l15 == 0) {
@@ -57,7 +70,10 @@ __device__ __forceinline__ void cross_wave_sum(float *red, int wave, int l4, int
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = l4 * 4 + r;
-        v[r] = red[row] + red[TR + row] + red[2 * TR + row] + red[3 * TR + row];
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w * TR + row];
+        v[r] = t;
     }
 }
 
@@ -74,17 +90,20 @@ __device__ __forceinline__ void cross_wave_sum(float *red, int wave, int l4, int
 // forward on a small batch.  out [B]: q (critic) or mu = tanh(.) (actor).  dq_da [B] (critic, optional):
 // dQ/da = sum_j wq[j] * [z_j > 0] * wa[j], which is all of the critic the actor's gradient needs because the action
 // enters after LayerNorm2 (networks.py:62-66).
+// waves_per_eu(1,1): tell the scheduler NOT to trade the deep load pipelining for occupancy it cannot use anyway
+// (16 workgroups on 256 CUs); without it hipcc keeps ~60 VGPRs and issues the weight loads a few at a time
 template <bool CRITIC>
-__global__ __launch_bounds__(256) void k_fwd_small(const int n, const float *__restrict__ obs,
+__global__ __launch_bounds__(64 * NW) void k_fwd_small(const int n, const float *__restrict__ obs,
                                                    const float *__restrict__ action, const Weights W,
                                                    float *__restrict__ out, const Saved sv, float *__restrict__ dq_da) {
     __shared__ __attribute__((aligned(16))) float h1_s[TR * HS1];     // [16][404]: A operand of layer 2
-    __shared__ float red[4 * TR];
+    __shared__ float red[NW * TR];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int row0 = blockIdx.x * TR;
 
-    // ---- layer 1 (K = 23): operands straight from global; this wave's column tiles t = wave, wave+4, ...
-    constexpr int MT1 = 7;
+    STAMP(0);
+    // ---- layer 1 (K = 23): operands straight from global; this wave's column tiles t = wave, wave+NW, ...
+    constexpr int MT1 = (NT1 + NW - 1) / NW;
     f32x4 acc1[MT1];
 #pragma unroll
     for (int i = 0; i < MT1; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -97,7 +116,7 @@ __global__ __launch_bounds__(256) void k_fwd_small(const int n, const float *__r
         }
 #pragma unroll
         for (int i = 0; i < MT1; ++i) {
-            const int t = wave + 4 * i;
+            const int t = wave + NW * i;
             if (t < NT1) {
                 float b[INP / 4];
 #pragma unroll
@@ -110,10 +129,11 @@ __global__ __launch_bounds__(256) void k_fwd_small(const int n, const float *__r
             }
         }
     }
+    STAMP(1);
     float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MT1; ++i) {
-        const int t = wave + 4 * i;
+        const int t = wave + NW * i;
         if (t < NT1) {
             const float bias = W.b1[t * 16 + l15];
 #pragma unroll
@@ -128,7 +148,7 @@ __global__ __launch_bounds__(256) void k_fwd_small(const int n, const float *__r
     for (int r = 0; r < 4; ++r) mean[r] = s[r] * (1.f / H1);
 #pragma unroll
     for (int i = 0; i < MT1; ++i) {
-        if (wave + 4 * i < NT1) {
+        if (wave + NW * i < NT1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float d = acc1[i][r] - mean[r]; ss[r] = fmaf(d, d, ss[r]); }
         }
@@ -145,7 +165,7 @@ __global__ __launch_bounds__(256) void k_fwd_small(const int n, const float *__r
     }
 #pragma unroll
     for (int i = 0; i < MT1; ++i) {
-        const int t = wave + 4 * i;
+        const int t = wave + NW * i;
         if (t < NT1) {
             const int col = t * 16 + l15;
             const float g = W.g1[col], be = W.be1[col];
@@ -163,10 +183,12 @@ __global__ __launch_bounds__(256) void k_fwd_small(const int n, const float *__r
         }
     }
     __syncthreads();   // the 16 x 400 activation tile is complete
+    STAMP(2);
 
-    // ---- layer 2: this wave's 5 column tiles; A from the LDS tile (one ds_read_b128 per k16 step), B = fc2 rows
-    // straight from L2 (one float4 per tile per k16 step), k visited in the permuted order described above
-    constexpr int MT2 = NT2 / 4;
+    // ---- layer 2: this wave's column tiles t = wave, wave+NW, ... (3 or 2 of the 20); A from the LDS tile (one
+    // ds_read_b128 per k16 step), B = fc2 rows straight from L2 (one float4 per tile per k16 step), k visited in
+    // the permuted order described above
+    constexpr int MT2 = (NT2 + NW - 1) / NW;
     f32x4 acc2[MT2];
 #pragma unroll
     for (int i = 0; i < MT2; ++i) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -174,54 +196,39 @@ __global__ __launch_bounds__(256) void k_fwd_small(const int n, const float *__r
     bool wreal[MT2];
 #pragma unroll
     for (int i = 0; i < MT2; ++i) {
-        const int nn = (wave * MT2 + i) * 16 + l15;
-        wreal[i] = nn < H2;
+        const int nn = (wave + NW * i) * 16 + l15;
+        wreal[i] = wave + NW * i < NT2 && nn < H2;
         wrow[i] = W.w2 + (size_t)(wreal[i] ? nn : 0) * H1 + 4 * l4;
     }
     const float *arow = h1_s + l15 * HS1 + 4 * l4;
-    // software pipeline: the B fragments of super-step ss+1 (5 k16 steps x 5 tiles = 25 float4 per lane) are in
-    // flight from L2 while the 100 MFMAs of super-step ss issue
-    constexpr int SS = 5;
-    struct BFrag { float4 v[SS][MT2]; };
-    auto load_b = [&](int ss) {
-        BFrag f;
+#pragma unroll 5
+    for (int c = 0; c < H1 / 16; ++c) {
+        const float4 av = *reinterpret_cast<const float4 *>(arow + 16 * c);
+        float4 bv[MT2];
 #pragma unroll
-        for (int st = 0; st < SS; ++st)
-#pragma unroll
-            for (int i = 0; i < MT2; ++i) {
-                f.v[st][i] = *reinterpret_cast<const float4 *>(wrow[i] + 16 * (ss * SS + st));
-                if (!wreal[i]) f.v[st][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        return f;
-    };
-    BFrag cur = load_b(0);
-#pragma unroll
-    for (int ss = 0; ss < H1 / 16 / SS; ++ss) {
-        BFrag nxt = cur;
-        if (ss + 1 < H1 / 16 / SS) nxt = load_b(ss + 1);
-#pragma unroll
-        for (int st = 0; st < SS; ++st) {
-            const float4 av = *reinterpret_cast<const float4 *>(arow + 16 * (ss * SS + st));
-            // ks-major: consecutive MFMAs write different accumulators (dependent latency 40 > issue 32 cycles)
-#pragma unroll
-            for (int i = 0; i < MT2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, cur.v[st][i].x, acc2[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < MT2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, cur.v[st][i].y, acc2[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < MT2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, cur.v[st][i].z, acc2[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < MT2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, cur.v[st][i].w, acc2[i], 0, 0, 0);
+        for (int i = 0; i < MT2; ++i) {
+            bv[i] = *reinterpret_cast<const float4 *>(wrow[i] + 16 * c);
+            if (!wreal[i]) bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        cur = nxt;
+        // ks-major: consecutive MFMAs write different accumulators (dependent latency 40 > issue 32 cycles)
+#pragma unroll
+        for (int i = 0; i < MT2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[i].x, acc2[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[i].y, acc2[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[i].z, acc2[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[i].w, acc2[i], 0, 0, 0);
     }
 
+    STAMP(3);
     // ---- epilogue
 #pragma unroll
     for (int r = 0; r < 4; ++r) s[r] = 0.f;
 #pragma unroll
     for (int i = 0; i < MT2; ++i) {
-        const int col = (wave * MT2 + i) * 16 + l15;
-        const bool real = col < H2;
+        const int col = (wave + NW * i) * 16 + l15;
+        const bool real = wave + NW * i < NT2 && col < H2;
         const float bias = real ? W.b2[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { acc2[i][r] = real ? acc2[i][r] + bias : 0.f; s[r] += acc2[i][r]; }
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(256) void k_fwd_small(const int n, const float *__r
     for (int r = 0; r < 4; ++r) { mean[r] = s[r] * (1.f / H2); ss[r] = 0.f; }
 #pragma unroll
     for (int i = 0; i < MT2; ++i) {
-        const bool real = (wave * MT2 + i) * 16 + l15 < H2;
+        const bool real = wave + NW * i < NT2 && (wave + NW * i) * 16 + l15 < H2;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const float d = real ? acc2[i][r] - mean[r] : 0.f; ss[r] = fmaf(d, d, ss[r]); }
     }
@@ -258,8 +265,8 @@ __global__ __launch_bounds__(256) void k_fwd_small(const int n, const float *__r
     float dot[4] = {0.f, 0.f, 0.f, 0.f}, dqa[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MT2; ++i) {
-        const int col = (wave * MT2 + i) * 16 + l15;
-        if (col < H2) {
+        const int col = (wave + NW * i) * 16 + l15;
+        if (wave + NW * i < NT2 && col < H2) {
             const float g = W.g2[col], be = W.be2[col], w3 = W.w3[col];
             float wa = 0.f, ba = 0.f;
             if (CRITIC) { wa = W.wa[col]; ba = W.ba[col]; }
@@ -299,6 +306,7 @@ __global__ __launch_bounds__(256) void k_fwd_small(const int n, const float *__r
             }
         }
     }
+    STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -313,7 +321,7 @@ constexpr int DS = 308;                       // LDS row stride of the dX2 tile 
 constexpr int NG = 7;                         // 64-column groups covering the 400 columns of dH1 (the last is partial)
 
 struct BwdOut {
-    float *dpre, *dz, *dx2, *dy1, *dx1;
+    float *__restrict__ dpre, *__restrict__ dz, *__restrict__ dx2, *__restrict__ dy1, *__restrict__ dx1;
 };
 
 __device__ __forceinline__ float wave_sum64(float v) {
@@ -327,18 +335,19 @@ __device__ __forceinline__ float wave_sum64(float v) {
 }
 
 template <bool CRITIC>
-__global__ __launch_bounds__(256) void k_bwd_rows(const int n, const int mode, const float scale,
-                                                  const float *__restrict__ d_out, const float *__restrict__ out,
-                                                  const float *__restrict__ y, const float *__restrict__ aux,
-                                                  const Weights W, const Saved sv, const BwdOut o) {
+__global__ __launch_bounds__(64 * NW) void k_bwd_rows(const int n, const int mode, const float scale,
+                                                      const float *__restrict__ d_out, const float *__restrict__ out,
+                                                      const float *__restrict__ y, const float *__restrict__ aux,
+                                                      const Weights W, const Saved sv, const BwdOut o) {
     __shared__ __attribute__((aligned(16))) float dx2_s[TR * DS];    // [16][308]
-    __shared__ float red[4 * TR];
+    __shared__ float red[NW * TR];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int row0 = blockIdx.x * TR;
-
-    // ---- phase A: head, ReLU and LayerNorm2 backward; wave w owns rows 4w .. 4w+3, lanes stride the 300 columns
-    for (int rr = 0; rr < 4; ++rr) {
-        const int lr = wave * 4 + rr, row = row0 + lr;
+    STAMP(8);
+    // ---- phase A: head, ReLU and LayerNorm2 backward; wave w owns rows 2w, 2w+1; lanes stride the 300 columns
+#pragma unroll
+    for (int rr = 0; rr < TR / NW; ++rr) {
+        const int lr = wave * (TR / NW) + rr, row = row0 + lr;
         float dpre = 0.f;
         if (row < n) {
             float g = mode == 0 ? d_out[row] : (mode == 1 ? scale * (out[row] - y[row]) : scale * aux[row]);
@@ -378,109 +387,78 @@ __global__ __launch_bounds__(256) void k_bwd_rows(const int n, const int mode, c
         if (lane == 0 && row < n) o.dpre[row] = dpre;
     }
     __syncthreads();
-
-    // ---- phase B: dH1 [16,400] = dX2 [16,304] * W2 [304,400].  Wave w owns the 64-column groups w and w+4; within a
+    STAMP(9);
+    // ---- phase B: dH1 [16,400] = dX2 [16,304] * W2 [304,400].  Wave w (< 7) owns the 64-column group w; within the
     // group, output tile t holds columns c0 + 4*(l&15) + t (one float4 of a W2 row feeds the 4 tiles).
-    f32x4 acc[2][4];
+    f32x4 acc[4];
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float *arow = dx2_s + l15 * DS + 4 * l4;
-    // software pipeline over groups of 3 k16 steps: 24 float4 rows of fc2 per lane in flight while 96 MFMAs issue
-    constexpr int GS = 3, NGRP = (H2K / 16 + GS - 1) / GS;        // 19 steps -> 7 groups (the last holds 1)
-    struct BFrag { float4 v[GS][4][2]; };
-    const bool gok[2] = {wave < NG && wave * 64 + 4 * l15 < H1, wave + 4 < NG && (wave + 4) * 64 + 4 * l15 < H1};
-    const float *wcol[2] = {W.w2 + (gok[0] ? wave * 64 + 4 * l15 : 0), W.w2 + (gok[1] ? (wave + 4) * 64 + 4 * l15 : 0)};
-    auto load_b = [&](int grp) {
-        BFrag f;
-#pragma unroll
-        for (int st = 0; st < GS; ++st)
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int c0 = wave * 64 + 4 * l15;
+    const bool gok = wave < NG && c0 < H1;
+    if (wave < NG) {
+        const float *arow = dx2_s + l15 * DS + 4 * l4;
+        const float *wcol = W.w2 + (gok ? c0 : 0);
+#pragma unroll 3
+        for (int c = 0; c < H2K / 16; ++c) {
+            const float4 av4 = *reinterpret_cast<const float4 *>(arow + 16 * c);
+            float4 bv[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int j = 16 * (grp * GS + st) + 4 * l4 + ks;      // row of fc2 = the k of this product
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    f.v[st][ks][g] = (gok[g] && j < H2) ? *reinterpret_cast<const float4 *>(wcol[g] + (size_t)j * H1)
-                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int j = 16 * c + 4 * l4 + ks;          // row of fc2 = the k of this product
+                bv[ks] = (gok && j < H2) ? *reinterpret_cast<const float4 *>(wcol + (size_t)j * H1)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        return f;
-    };
-    BFrag cur = load_b(0);
+            const float a[4] = {av4.x, av4.y, av4.z, av4.w};
 #pragma unroll
-    for (int grp = 0; grp < NGRP; ++grp) {
-        BFrag nxt = cur;
-        if (grp + 1 < NGRP) nxt = load_b(grp + 1);
-#pragma unroll
-        for (int st = 0; st < GS; ++st) {
-            const int c = grp * GS + st;
-            if (c < H2K / 16) {
-                const float4 av4 = *reinterpret_cast<const float4 *>(arow + 16 * c);
-                const float a[4] = {av4.x, av4.y, av4.z, av4.w};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        if (wave + 4 * g < NG) {
-                            const float4 bv = cur.v[st][ks][g];
-                            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv.x, acc[g][0], 0, 0, 0);
-                            acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv.y, acc[g][1], 0, 0, 0);
-                            acc[g][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv.z, acc[g][2], 0, 0, 0);
-                            acc[g][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv.w, acc[g][3], 0, 0, 0);
-                        }
-                    }
+            for (int ks = 0; ks < 4; ++ks) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv[ks].x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv[ks].y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv[ks].z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv[ks].w, acc[3], 0, 0, 0);
             }
         }
-        cur = nxt;
     }
-
-    // ---- phase C: ReLU and LayerNorm1 backward; accumulator [g][t][r] is row l4*4+r, column grp*64 + 4*l15 + t
-    float xh1[2][4][4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    STAMP(10);
+    // ---- phase C: ReLU and LayerNorm1 backward; accumulator [t][r] is row l4*4+r, column wave*64 + 4*l15 + t
+    float xh1[4][4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int c0 = (wave + 4 * g) * 64 + 4 * l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + l4 * 4 + r;
-            float4 h = make_float4(0.f, 0.f, 0.f, 0.f), x = h, gm = h;
-            const bool ok = wave + 4 * g < NG && c0 < H1 && row < n;
-            if (ok) {
-                h = *reinterpret_cast<const float4 *>(sv.h1 + (size_t)row * H1 + c0);
-                x = *reinterpret_cast<const float4 *>(sv.xh1 + (size_t)row * H1 + c0);
-                gm = *reinterpret_cast<const float4 *>(W.g1 + c0);
-            }
-            const float hh[4] = {h.x, h.y, h.z, h.w}, xx[4] = {x.x, x.y, x.z, x.w}, gg[4] = {gm.x, gm.y, gm.z, gm.w};
-            float dy[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                dy[t] = (ok && hh[t] > 0.f) ? acc[g][t][r] : 0.f;
-                xh1[g][t][r] = xx[t];
-                acc[g][t][r] = dy[t] * gg[t];                // d(x-hat)
-                s1[r] += acc[g][t][r];
-                s2[r] = fmaf(acc[g][t][r], xx[t], s2[r]);
-            }
-            if (ok) *reinterpret_cast<float4 *>(o.dy1 + (size_t)row * H1 + c0) = make_float4(dy[0], dy[1], dy[2], dy[3]);
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + l4 * 4 + r;
+        float4 h = make_float4(0.f, 0.f, 0.f, 0.f), x = h, gm = h;
+        const bool ok = gok && row < n;
+        if (ok) {
+            h = *reinterpret_cast<const float4 *>(sv.h1 + (size_t)row * H1 + c0);
+            x = *reinterpret_cast<const float4 *>(sv.xh1 + (size_t)row * H1 + c0);
+            gm = *reinterpret_cast<const float4 *>(W.g1 + c0);
         }
+        const float hh[4] = {h.x, h.y, h.z, h.w}, xx[4] = {x.x, x.y, x.z, x.w}, gg[4] = {gm.x, gm.y, gm.z, gm.w};
+        float dy[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            dy[t] = (ok && hh[t] > 0.f) ? acc[t][r] : 0.f;
+            xh1[t][r] = xx[t];
+            acc[t][r] = dy[t] * gg[t];                       // d(x-hat)
+            s1[r] += acc[t][r];
+            s2[r] = fmaf(acc[t][r], xx[t], s2[r]);
+        }
+        if (ok) *reinterpret_cast<float4 *>(o.dy1 + (size_t)row * H1 + c0) = make_float4(dy[0], dy[1], dy[2], dy[3]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[r] = row_sum16(s1[r]); s2[r] = row_sum16(s2[r]); }
     cross_wave_sum(red, wave, l4, l15, s1);
     cross_wave_sum(red, wave, l4, l15, s2);
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int c0 = (wave + 4 * g) * 64 + 4 * l15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + l4 * 4 + r;
+        if (gok && row < n) {
+            const float rs = sv.rstd1[row], m1 = s1[r] * (1.f / H1), m2 = s2[r] * (1.f / H1);
+            float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + l4 * 4 + r;
-            if (wave + 4 * g < NG && c0 < H1 && row < n) {
-                const float rs = sv.rstd1[row], m1 = s1[r] * (1.f / H1), m2 = s2[r] * (1.f / H1);
-                float v[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = rs * (acc[g][t][r] - m1 - xh1[g][t][r] * m2);
-                *reinterpret_cast<float4 *>(o.dx1 + (size_t)row * H1 + c0) = make_float4(v[0], v[1], v[2], v[3]);
-            }
+            for (int t = 0; t < 4; ++t) v[t] = rs * (acc[t][r] - m1 - xh1[t][r] * m2);
+            *reinterpret_cast<float4 *>(o.dx1 + (size_t)row * H1 + c0) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
+    STAMP(11);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -490,7 +468,8 @@ __global__ __launch_bounds__(256) void k_bwd_rows(const int n, const int mode, c
 //   then              column sums (db2, dg2, dbe2, db1, dg1, dbe1, dw3, db3, critic: dwa, dba): a workgroup sums 64
 //                     columns, its 4 waves take a quarter of the rows each, combined through LDS
 struct Grads {
-    float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *w3, *b3, *wa, *ba;
+    float *__restrict__ w1, *__restrict__ b1, *__restrict__ g1, *__restrict__ be1, *__restrict__ w2, *__restrict__ b2,
+        *__restrict__ g2, *__restrict__ be2, *__restrict__ w3, *__restrict__ b3, *__restrict__ wa, *__restrict__ ba;
 };
 constexpr int JT2 = (H2 + 15) / 16;                 // 19 row tiles of dW2
 constexpr int WB2 = (JT2 * NG + 3) / 4;             // 34 workgroups
@@ -518,7 +497,7 @@ __device__ __forceinline__ float colsum_term(const int q, const int b, const Sav
     return which == 0 ? dz * action[b] : dz;
 }
 
-__global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int critic, const float *__restrict__ obs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_bwd_weights(const int n, const int critic, const float *__restrict__ obs,
                                                      const float *__restrict__ action, const Saved sv,
                                                      const BwdOut d, const Grads G) {
     __shared__ float part[4][64];
@@ -553,6 +532,7 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
         for (int b0 = 0; b0 < n; b0 += 16 * GW) {
             Frag nxt = cur;
             if (b0 + 16 * GW < n) nxt = load_f(b0 + 16 * GW);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int st = 0; st < GW; ++st)
 #pragma unroll
@@ -700,7 +680,7 @@ int tt_mlp_forward_save(int n, int critic, const float *obs, const float *action
         if (!saved->xh1 || !saved->h1 || !saved->xh2 || !saved->h2 || !saved->rstd1 || !saved->rstd2) return TT_EINVAL;
         sv = Saved{saved->xh1, saved->h1, saved->xh2, saved->h2, saved->rstd1, saved->rstd2};
     }
-    const dim3 grid((n + TR - 1) / TR), block(256);
+    const dim3 grid((n + TR - 1) / TR), block(64 * NW);
     if (critic)
         hipLaunchKernelGGL(k_fwd_small<true>, grid, block, 0, stream, n, obs, action, to_weights(w), out, sv, dq_da);
     else
@@ -719,12 +699,12 @@ int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, 
         return TT_EINVAL;
     const Saved sv{saved->xh1, saved->h1, saved->xh2, saved->h2, saved->rstd1, saved->rstd2};
     const BwdOut o{ws->dpre, ws->dz, ws->dx2, ws->dy1, ws->dx1};
-    const dim3 grid((n + TR - 1) / TR), block(256);
+    const dim3 grid((n + TR - 1) / TR), block(256), block_rows(64 * NW);
     if (critic)
-        hipLaunchKernelGGL(k_bwd_rows<true>, grid, block, 0, stream, n, mode, scale, d_out, out, y, aux,
+        hipLaunchKernelGGL(k_bwd_rows<true>, grid, block_rows, 0, stream, n, mode, scale, d_out, out, y, aux,
                            to_weights(w), sv, o);
     else
-        hipLaunchKernelGGL(k_bwd_rows<false>, grid, block, 0, stream, n, mode, scale, d_out, out, y, aux,
+        hipLaunchKernelGGL(k_bwd_rows<false>, grid, block_rows, 0, stream, n, mode, scale, d_out, out, y, aux,
                            to_weights(w), sv, o);
     if (hipGetLastError() != hipSuccess) return TT_EHIP;
     const Grads G{const_cast<float *>(grads->w1), const_cast<float *>(grads->b1), const_cast<float *>(grads->g1),
@@ -756,6 +736,12 @@ int tt_adam_soft_update(int count, float *const *params, const float *const *gra
                        beta1, beta2, eps, weight_decay, tau);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
+
+#ifdef TT_STAMPS
+int tt_debug_stamps(unsigned long long *out32) {
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -3;
+}
+#endif
 
 int tt_td_target(int n, const float *reward, const float *q_next, const uint8_t *done, float gamma, float *y,
                  int64_t *step_dev, tt_stream_t stream) {
