@@ -33,8 +33,10 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #ifdef TT_STAMPS   // diagnostic build only: wall-clock stamps (100 MHz) of workgroup 0 / wave 0 at phase boundaries
 __device__ unsigned long long g_stamps[32];
 #define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_stamps[i] = wall_clock64(); g_stamps[16 + i] = clock64(); } } while (0)
+#define STAMPB(i, blk0) do { if ((int)blockIdx.x == (blk0) && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMPB(i, blk0) do { } while (0)
 #endif
 
 // __restrict__ on the members: none of these buffers alias, and without it every store (saved activations,
@@ -462,145 +464,145 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows(const int n, const int mod
 }
 
 // ------------------------------------------------------------------------------------------------------
-// weight gradients.  Workgroup roles by blockIdx (one wave = one output block, K = batch in permuted k16 steps):
-//   [0, WB2)          dW2 [300,400] = dX2^T * H1: wave -> (16 rows j) x (64-column group); 19 x 7 = 133 waves
-//   [WB2, WB2+WB1)    dW1 [400,23]  = dX1^T * S : wave -> 16 rows j x 2 column tiles; 25 waves
-//   then              column sums (db2, dg2, dbe2, db1, dg1, dbe1, dw3, db3, critic: dwa, dba): a workgroup sums 64
-//                     columns, its 4 waves take a quarter of the rows each, combined through LDS
+// weight gradients.  Workgroup roles by blockIdx; K = batch in permuted k16 steps, SPLIT over the 4 waves of the
+// workgroup (each wave takes a quarter of the batch rows, all its loads are independent and issued together), the
+// four partial tiles are then added through LDS in a fixed order (deterministic, no atomics):
+//   [0, NU2)            dW2 [300,400] = dX2^T * H1: one (16 rows j) x (64-column group) block per workgroup; 19 x 7
+//   [NU2, NU2+NU1)      dW1 [400,23]  = dX1^T * S : 16 rows j x 2 column tiles per workgroup; 25
+//   then                column sums (db2, dg2, dbe2, db1, dg1, dbe1, dw3, db3, critic: dwa, dba): a workgroup sums 64
+//                       columns, its 4 waves a quarter of the rows each
 struct Grads {
     float *__restrict__ w1, *__restrict__ b1, *__restrict__ g1, *__restrict__ be1, *__restrict__ w2, *__restrict__ b2,
         *__restrict__ g2, *__restrict__ be2, *__restrict__ w3, *__restrict__ b3, *__restrict__ wa, *__restrict__ ba;
 };
 constexpr int JT2 = (H2 + 15) / 16;                 // 19 row tiles of dW2
-constexpr int WB2 = (JT2 * NG + 3) / 4;             // 34 workgroups
-constexpr int WB1 = (H1 / 16 + 3) / 4;              // 7 workgroups (25 waves)
+constexpr int NU2 = JT2 * NG;                       // 133 workgroups
+constexpr int NU1 = H1 / 16;                        // 25 workgroups
 constexpr int NSUM = 3 * H2 + 3 * H1 + H2 + 1 + 2 * H2;   // 3001 column-sum outputs (the last 600 critic only)
 
 __device__ __forceinline__ float colsum_term(const int q, const int b, const Saved &sv, const BwdOut &d,
-                                             const float *__restrict__ action, float *&dst, int &c, bool &valid) {
+                                             const float *__restrict__ action) {
     // q indexes the concatenation [db2 | dg2 | dbe2 | db1 | dg1 | dbe1 | dw3 | db3 | dwa | dba]
-    valid = true;
     if (q < 3 * H2) {
-        const int which = q / H2; c = q - which * H2;
+        const int which = q / H2, c = q - which * H2;
         const size_t p = (size_t)b * H2 + c;
         return which == 0 ? d.dx2[p] : (which == 1 ? d.dz[p] * sv.xh2[p] : d.dz[p]);
     }
     if (q < 3 * H2 + 3 * H1) {
-        const int qq = q - 3 * H2, which = qq / H1; c = qq - which * H1;
+        const int qq = q - 3 * H2, which = qq / H1, c = qq - which * H1;
         const size_t p = (size_t)b * H1 + c;
         return which == 0 ? d.dx1[p] : (which == 1 ? d.dy1[p] * sv.xh1[p] : d.dy1[p]);
     }
-    if (q < 3 * H2 + 3 * H1 + H2) { c = q - 3 * H2 - 3 * H1; return d.dpre[b] * sv.h2[(size_t)b * H2 + c]; }
-    if (q == 3 * H2 + 3 * H1 + H2) { c = 0; return d.dpre[b]; }
-    const int qq = q - (3 * H2 + 3 * H1 + H2 + 1), which = qq / H2; c = qq - which * H2;
+    if (q < 3 * H2 + 3 * H1 + H2) return d.dpre[b] * sv.h2[(size_t)b * H2 + (q - 3 * H2 - 3 * H1)];
+    if (q == 3 * H2 + 3 * H1 + H2) return d.dpre[b];
+    const int qq = q - (3 * H2 + 3 * H1 + H2 + 1), which = qq / H2, c = qq - which * H2;
     const float dz = d.dz[(size_t)b * H2 + c];
     return which == 0 ? dz * action[b] : dz;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_bwd_weights(const int n, const int critic, const float *__restrict__ obs,
+__global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int critic, const float *__restrict__ obs,
                                                      const float *__restrict__ action, const Saved sv,
                                                      const BwdOut d, const Grads G) {
-    __shared__ float part[4][64];
+    __shared__ __attribute__((aligned(16))) float part[4][4][256];     // [wave][tile][lane*4 + r]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int blk = blockIdx.x;
-    if (blk < WB2) {
-        const int unit = blk * 4 + wave;
-        if (unit >= JT2 * NG) return;
-        const int jt = unit / NG, grp = unit - jt * NG;
+    STAMPB(12, 0); STAMPB(14, NU2); STAMPB(5, NU2 + NU1);
+    const int rows_w = (((n + 3) / 4) + 15) / 16 * 16;                  // batch rows per wave, whole k16 steps
+    const int b_lo = wave * rows_w, b_hi = min(n, b_lo + rows_w);
+    if (blk < NU2) {
+        const int jt = blk / NG, grp = blk - jt * NG;
         const int j = jt * 16 + l15, c0 = grp * 64 + 4 * l15;
         const bool jok = j < H2, cok = c0 < H1;
         f32x4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // software pipeline over groups of 4 k16 steps (64 batch rows): 16 scalars + 16 float4 per lane in flight
-        constexpr int GW = 4;
-        struct Frag { float a[GW][4]; float4 b[GW][4]; };
-        auto load_f = [&](int b0) {
-            Frag f;
+        for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
+            float av[4];
+            float4 bv[4];
 #pragma unroll
-            for (int st = 0; st < GW; ++st)
+            for (int ks = 0; ks < 4; ++ks) {
+                const int b = b0 + 4 * l4 + ks;                                          // permuted k order
+                av[ks] = (b < b_hi && jok) ? d.dx2[(size_t)b * H2 + j] : 0.f;           // A[i = j][k = b]
+                bv[ks] = (b < b_hi && cok) ? *reinterpret_cast<const float4 *>(sv.h1 + (size_t)b * H1 + c0)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int b = b0 + 16 * st + 4 * l4 + ks;                            // permuted k order
-                    f.a[st][ks] = (b < n && jok) ? d.dx2[(size_t)b * H2 + j] : 0.f;      // A[i = j][k = b]
-                    f.b[st][ks] = (b < n && cok) ? *reinterpret_cast<const float4 *>(sv.h1 + (size_t)b * H1 + c0)
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            return f;
-        };
-        Frag cur = load_f(0);
-        for (int b0 = 0; b0 < n; b0 += 16 * GW) {
-            Frag nxt = cur;
-            if (b0 + 16 * GW < n) nxt = load_f(b0 + 16 * GW);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int st = 0; st < GW; ++st)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const float a = cur.a[st][ks];
-                    const float4 bv = cur.b[st][ks];
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv.x, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv.y, acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv.z, acc[2], 0, 0, 0);
-                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv.w, acc[3], 0, 0, 0);
-                }
-            cur = nxt;
+            for (int ks = 0; ks < 4; ++ks) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks].x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks].y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks].z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks].w, acc[3], 0, 0, 0);
+            }
         }
-        if (cok) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4 *>(&part[wave][t][lane * 4]) = acc[t];
+        __syncthreads();
+        // wave w finishes output tile t = w: sum the four K-quarters in a fixed order
+        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(&part[0][wave][lane * 4]);
+        const f32x4 p1 = *reinterpret_cast<const f32x4 *>(&part[1][wave][lane * 4]);
+        const f32x4 p2 = *reinterpret_cast<const f32x4 *>(&part[2][wave][lane * 4]);
+        const f32x4 p3 = *reinterpret_cast<const f32x4 *>(&part[3][wave][lane * 4]);
+        const int col = grp * 64 + 4 * l15 + wave;                       // tile t holds columns c0 + t
+        if (col < H1 && grp * 64 + 4 * l15 < H1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int jr = jt * 16 + l4 * 4 + r;
-                if (jr < H2)
-                    *reinterpret_cast<float4 *>(G.w2 + (size_t)jr * H1 + c0) =
-                        make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+                if (jr < H2) G.w2[(size_t)jr * H1 + col] = ((p0[r] + p1[r]) + p2[r]) + p3[r];
             }
         }
-    } else if (blk < WB2 + WB1) {
-        const int jt = (blk - WB2) * 4 + wave;
-        if (jt >= H1 / 16) return;
-        const int j = jt * 16 + l15;
+        STAMPB(13, 0);
+    } else if (blk < NU2 + NU1) {
+        const int jt = blk - NU2, j = jt * 16 + l15;
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll 4
-        for (int b0 = 0; b0 < n; b0 += 16) {
+        for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
+            float av[4], b0v[4], b1v[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int b = b0 + 4 * l4 + ks;
-                const float a = b < n ? d.dx1[(size_t)b * H1 + j] : 0.f;
-                const float b0v = b < n ? obs[(size_t)b * IN + l15] : 0.f;                  // columns 0..15
-                const float b1v = (b < n && 16 + l15 < IN) ? obs[(size_t)b * IN + 16 + l15] : 0.f;   // 16..22
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0v, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1v, acc[1], 0, 0, 0);
+                av[ks] = b < b_hi ? d.dx1[(size_t)b * H1 + j] : 0.f;
+                b0v[ks] = b < b_hi ? obs[(size_t)b * IN + l15] : 0.f;                            // columns 0..15
+                b1v[ks] = (b < b_hi && 16 + l15 < IN) ? obs[(size_t)b * IN + 16 + l15] : 0.f;    // 16..22
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], b0v[ks], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], b1v[ks], acc[1], 0, 0, 0);
             }
         }
+        *reinterpret_cast<f32x4 *>(&part[wave][0][lane * 4]) = acc[0];
+        *reinterpret_cast<f32x4 *>(&part[wave][1][lane * 4]) = acc[1];
+        __syncthreads();
+        if (wave < 2) {
+            const int col = wave * 16 + l15;
+            if (col < IN) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int jr = jt * 16 + l4 * 4 + r;
-            G.w1[(size_t)jr * IN + l15] = acc[0][r];
-            if (16 + l15 < IN) G.w1[(size_t)jr * IN + 16 + l15] = acc[1][r];
+                for (int r = 0; r < 4; ++r)
+                    G.w1[(size_t)(jt * 16 + l4 * 4 + r) * IN + col] =
+                        ((part[0][wave][lane * 4 + r] + part[1][wave][lane * 4 + r]) + part[2][wave][lane * 4 + r]) +
+                        part[3][wave][lane * 4 + r];
+            }
         }
+        STAMPB(15, NU2);
     } else {
-        const int q = (blk - WB2 - WB1) * 64 + lane;
+        const int q = (blk - NU2 - NU1) * 64 + lane;
         const int limit = critic ? NSUM : NSUM - 2 * H2;
         float acc = 0.f;
-        float *dst = nullptr;
-        int c = 0;
-        bool valid = false;
         if (q < limit) {
-            const int rows = (n + 3) / 4, b_lo = wave * rows, b_hi = min(n, b_lo + rows);
-            int b = b_lo;
-            for (; b + 8 <= b_hi; b += 8) {               // 8 independent loads in flight, then one add chain
-                float t[8];
+            const int rows = (n + 3) / 4, lo = wave * rows, hi = min(n, lo + rows);
+            int b = lo;
+            for (; b + 16 <= hi; b += 16) {               // 16 independent loads in flight, then one add chain
+                float t[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = colsum_term(q, b + u, sv, d, action, dst, c, valid);
+                for (int u = 0; u < 16; ++u) t[u] = colsum_term(q, b + u, sv, d, action);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += t[u];
+                for (int u = 0; u < 16; ++u) acc += t[u];
             }
-            for (; b < b_hi; ++b) acc += colsum_term(q, b, sv, d, action, dst, c, valid);
+            for (; b < hi; ++b) acc += colsum_term(q, b, sv, d, action);
         }
-        part[wave][lane] = acc;
+        part[wave][0][lane] = acc;
         __syncthreads();
         if (wave == 0 && q < limit) {
-            const float total = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+            const float total = ((part[0][0][lane] + part[1][0][lane]) + part[2][0][lane]) + part[3][0][lane];
             float *out;
             int cc;
             if (q < 3 * H2) { const int which = q / H2; cc = q - which * H2; out = which == 0 ? G.b2 : (which == 1 ? G.g2 : G.be2); }
@@ -610,6 +612,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             else { const int qq = q - (3 * H2 + 3 * H1 + H2 + 1), which = qq / H2; cc = qq - which * H2; out = which == 0 ? G.wa : G.ba; }
             out[cc] = total;
         }
+        STAMPB(6, NU2 + NU1);
     }
 }
 
@@ -712,7 +715,7 @@ int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, 
                   const_cast<float *>(grads->g2), const_cast<float *>(grads->be2), const_cast<float *>(grads->w3),
                   const_cast<float *>(grads->b3), const_cast<float *>(grads->wa), const_cast<float *>(grads->ba)};
     const int sum_blocks = ((critic ? NSUM : NSUM - 2 * H2) + 63) / 64;
-    hipLaunchKernelGGL(k_bwd_weights, dim3(WB2 + WB1 + sum_blocks), block, 0, stream, n, critic, obs, action, sv, o, G);
+    hipLaunchKernelGGL(k_bwd_weights, dim3(NU2 + NU1 + sum_blocks), block, 0, stream, n, critic, obs, action, sv, o, G);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 
