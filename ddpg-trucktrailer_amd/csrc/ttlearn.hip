@@ -32,6 +32,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 #ifdef TT_STAMPS   // diagnostic build only: wall-clock stamps (100 MHz) of workgroup 0 / wave 0 at phase boundaries
 __device__ unsigned long long g_stamps[32];
+__device__ unsigned long long g_blk[512][2];
 #define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_stamps[i] = wall_clock64(); g_stamps[16 + i] = clock64(); } } while (0)
 #define STAMPB(i, blk0) do { if ((int)blockIdx.x == (blk0) && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
 #else
@@ -478,7 +479,9 @@ struct Grads {
 constexpr int JT2 = (H2 + 15) / 16;                 // 19 row tiles of dW2
 constexpr int NU2 = JT2 * NG;                       // 133 workgroups
 constexpr int NU1 = H1 / 16;                        // 25 workgroups
-constexpr int NSUM = 3 * H2 + 3 * H1 + H2 + 1 + 2 * H2;   // 3001 column-sum outputs (the last 600 critic only)
+constexpr int NCAT = 10;                            // db2 dg2 dbe2 db1 dg1 dbe1 dw3 db3 dwa dba
+constexpr int SUMB_ACTOR = 3 * 5 + 3 * 7 + 5 + 1;   // 64-column chunks per quantity: 300 -> 5, 400 -> 7, 1 -> 1
+constexpr int SUMB_CRITIC = SUMB_ACTOR + 2 * 5;
 
 __device__ __forceinline__ float colsum_term(const int q, const int b, const Saved &sv, const BwdOut &d,
                                              const float *__restrict__ action) {
@@ -507,6 +510,9 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int blk = blockIdx.x;
     STAMPB(12, 0); STAMPB(14, NU2); STAMPB(5, NU2 + NU1);
+#ifdef TT_STAMPS
+    if (threadIdx.x == 0) g_blk[blockIdx.x][0] = wall_clock64();
+#endif
     const int rows_w = (((n + 3) / 4) + 15) / 16 * 16;                  // batch rows per wave, whole k16 steps
     const int b_lo = wave * rows_w, b_hi = min(n, b_lo + rows_w);
     if (blk < NU2) {
@@ -551,6 +557,9 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
             }
         }
         STAMPB(13, 0);
+#ifdef TT_STAMPS
+        __syncthreads(); if (threadIdx.x == 0) g_blk[blockIdx.x][1] = wall_clock64();
+#endif
     } else if (blk < NU2 + NU1) {
         const int jt = blk - NU2, j = jt * 16 + l15;
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -583,12 +592,32 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
             }
         }
         STAMPB(15, NU2);
+#ifdef TT_STAMPS
+        __syncthreads(); if (threadIdx.x == 0) g_blk[blockIdx.x][1] = wall_clock64();
+#endif
     } else {
-        const int q = (blk - NU2 - NU1) * 64 + lane;
-        const int limit = critic ? NSUM : NSUM - 2 * H2;
+        // column sums.  Every workgroup handles 64 columns of ONE quantity (a wave straddling two quantities would run
+        // both row loops one after the other): [db2 dg2 dbe2 | db1 dg1 dbe1 | dw3 | db3 | dwa dba] in 64-column chunks
+        int cb = blk - NU2 - NU1;
+        int cat = -1, base = 0;
+#pragma unroll
+        for (int k = 0; k < NCAT; ++k) {
+            const int width = k < 3 ? H2 : (k < 6 ? H1 : (k == 7 ? 1 : H2));
+            const int nb = (width + 63) / 64;
+            if (cat < 0) {
+                if (cb < nb) { cat = k; base = width; }
+                else cb -= nb;
+            }
+        }
+        const int c = cb * 64 + lane;
+        const bool valid = cat >= 0 && c < base;
         float acc = 0.f;
-        if (q < limit) {
+        if (valid) {
             const int rows = (n + 3) / 4, lo = wave * rows, hi = min(n, lo + rows);
+            // q in the layout colsum_term() understands
+            const int q = cat < 3 ? cat * H2 + c : (cat < 6 ? 3 * H2 + (cat - 3) * H1 + c
+                          : (cat == 6 ? 3 * H2 + 3 * H1 + c : (cat == 7 ? 3 * H2 + 3 * H1 + H2
+                          : 3 * H2 + 3 * H1 + H2 + 1 + (cat - 8) * H2 + c)));
             int b = lo;
             for (; b + 16 <= hi; b += 16) {               // 16 independent loads in flight, then one add chain
                 float t[16];
@@ -601,18 +630,15 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
         }
         part[wave][0][lane] = acc;
         __syncthreads();
-        if (wave == 0 && q < limit) {
+        if (wave == 0 && valid) {
             const float total = ((part[0][0][lane] + part[1][0][lane]) + part[2][0][lane]) + part[3][0][lane];
-            float *out;
-            int cc;
-            if (q < 3 * H2) { const int which = q / H2; cc = q - which * H2; out = which == 0 ? G.b2 : (which == 1 ? G.g2 : G.be2); }
-            else if (q < 3 * H2 + 3 * H1) { const int qq = q - 3 * H2, which = qq / H1; cc = qq - which * H1; out = which == 0 ? G.b1 : (which == 1 ? G.g1 : G.be1); }
-            else if (q < 3 * H2 + 3 * H1 + H2) { cc = q - 3 * H2 - 3 * H1; out = G.w3; }
-            else if (q == 3 * H2 + 3 * H1 + H2) { cc = 0; out = G.b3; }
-            else { const int qq = q - (3 * H2 + 3 * H1 + H2 + 1), which = qq / H2; cc = qq - which * H2; out = which == 0 ? G.wa : G.ba; }
-            out[cc] = total;
+            float *const outs[NCAT] = {G.b2, G.g2, G.be2, G.b1, G.g1, G.be1, G.w3, G.b3, G.wa, G.ba};
+            outs[cat][c] = total;
         }
         STAMPB(6, NU2 + NU1);
+#ifdef TT_STAMPS
+        __syncthreads(); if (threadIdx.x == 0) g_blk[blockIdx.x][1] = wall_clock64();
+#endif
     }
 }
 
@@ -714,7 +740,7 @@ int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, 
                   const_cast<float *>(grads->be1), const_cast<float *>(grads->w2), const_cast<float *>(grads->b2),
                   const_cast<float *>(grads->g2), const_cast<float *>(grads->be2), const_cast<float *>(grads->w3),
                   const_cast<float *>(grads->b3), const_cast<float *>(grads->wa), const_cast<float *>(grads->ba)};
-    const int sum_blocks = ((critic ? NSUM : NSUM - 2 * H2) + 63) / 64;
+    const int sum_blocks = critic ? SUMB_CRITIC : SUMB_ACTOR;
     hipLaunchKernelGGL(k_bwd_weights, dim3(NU2 + NU1 + sum_blocks), block, 0, stream, n, critic, obs, action, sv, o, G);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
@@ -741,6 +767,9 @@ int tt_adam_soft_update(int count, float *const *params, const float *const *gra
 }
 
 #ifdef TT_STAMPS
+int tt_debug_blocks(unsigned long long *out1024) {
+    return hipMemcpyFromSymbol(out1024, HIP_SYMBOL(g_blk), sizeof(unsigned long long) * 1024) == hipSuccess ? 0 : -3;
+}
 int tt_debug_stamps(unsigned long long *out32) {
     return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -3;
 }
