@@ -33,7 +33,8 @@ class TTInfo(C.Structure):
 
 class TTMlpWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "w3", "b3", "wa", "ba")] + \
-               [("in_dim", C.c_int32), ("fc1_dims", C.c_int32), ("fc2_dims", C.c_int32), ("reserved_", C.c_int32)]
+               [("in_dim", C.c_int32), ("fc1_dims", C.c_int32), ("fc2_dims", C.c_int32), ("reserved_", C.c_int32),
+                ("split_ws", C.c_void_p)]
 
 
 class TTMlpSaved(C.Structure):
@@ -73,6 +74,7 @@ _SIGNATURES = {
     "tt_env_rollout_random": (C.c_int, [_P, _I, _U64, _P, _P, _P, _P]),
     "tt_env_profile": (C.c_int, [_P, _I]),
     "tt_env_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "tt_mlp_split_ws_bytes": (C.c_uint64, []),
     "tt_actor_forward": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_actor_act": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P, _U64, _U64, _P, C.c_float, C.c_float, C.c_float,
                                _P, _P, _P, _P]),

@@ -1,4 +1,5 @@
-"""Fused f32 inference of the reference-shaped actor / critic (csrc/ttnet.hip) behind torch tensors.
+"""Fused f32-accurate inference of the reference-shaped actor / critic (csrc/ttnet.hip, csrc/ttnet_split.hip) behind
+torch tensors.
 
 Used where no gradient is needed: the N-env `choose_action` of the rollout loop and the target-network
 forward passes of `learn()`.  Networks of other shapes (or CPU tensors) report `supported(net) == False` and the
@@ -36,6 +37,10 @@ def weights_of(net):
     if hasattr(net, "action_value"):
         w.wa, w.ba = net.action_value.weight.data_ptr(), net.action_value.bias.data_ptr()
     w.in_dim, w.fc1_dims, w.fc2_dims = 23, 400, 300
+    # workspace of the split-bf16 kernel (csrc/ttnet_split.hip), re-packed from fc2 by every call that uses it; one per
+    # module, so two streams never share one (the learner's side stream runs other modules)
+    net._tt_split_ws = torch.empty(int(L.load().tt_mlp_split_ws_bytes()), dtype=torch.uint8, device=net.fc2.weight.device)
+    w.split_ws = net._tt_split_ws.data_ptr()
     net._tt_weights = (key, w)
     return w
 

@@ -183,13 +183,21 @@ int tt_random_actions(int n, uint64_t seed, uint64_t step, float *out, tt_stream
 
 /* ------------------------------------------------------------------------------------------------------
  * Fused inference of the reference's networks (shapes of trainv2.py:404-407: 23 -> 400 -> 300 -> 1, LayerNorm
- * eps 1e-5), exact f32 on the f32-input MFMA.  Pointers are torch parameter storages (row-major [out,in]):
+ * eps 1e-5) at f32 accuracy.  Pointers are torch parameter storages (row-major [out,in]):
  *   w1 [400,23] b1 g1 be1 [400] = fc1, bn1;  w2 [300,400] b2 g2 be2 [300] = fc2, bn2;  w3 [300] b3 [1] = mu / q;
- *   wa [300] ba [300] = action_value (critic only).  Other shapes return TT_EINVAL (callers fall back to torch). */
+ *   wa [300] ba [300] = action_value (critic only).  Other shapes return TT_EINVAL (callers fall back to torch).
+ * Two kernels serve a forward: the exact-f32 MFMA kernel (csrc/ttnet.hip), and for n >= 1024 rows the split-bf16
+ * kernel (csrc/ttnet_split.hip: every f32 operand is the exact sum of three bf16 pieces, six bf16 MFMAs with f32
+ * accumulation per product block, error below the f32 product's own rounding) when split_ws is set: a caller-owned
+ * device workspace of tt_mlp_split_ws_bytes() bytes, one per network and per stream that may run it concurrently,
+ * into which each call re-packs fc2 before it runs (never stale; the contents are private to the library).
+ * split_ws = NULL always selects the exact-f32 kernel.  Structs of gradients (tt_mlp_backward) ignore it. */
 typedef struct tt_mlp_weights {
     const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *w3, *b3, *wa, *ba;
     int32_t in_dim, fc1_dims, fc2_dims, reserved_;
+    void *split_ws;
 } tt_mlp_weights;
+uint64_t tt_mlp_split_ws_bytes(void);
 
 /* ActorNetwork.forward (DDPG/networks.py:138-147) for n rows: mu_out [n] = tanh(mu(...)). */
 int tt_actor_forward(int n, const float *obs /*[n,23]*/, const tt_mlp_weights *w, float *mu_out, tt_stream_t stream);
