@@ -305,6 +305,10 @@ int launch(int n, const float *obs, const float *action, const tt_mlp_weights *w
 
 extern "C" {
 
+#ifdef TT_STAMPS
+int tt_debug_nstamps(unsigned long long *out16) { return ttnet::split_debug_stamps(out16); }
+#endif
+
 uint64_t tt_mlp_split_ws_bytes(void) { return (uint64_t)split_ws_bytes(); }
 
 

@@ -82,5 +82,8 @@ size_t split_ws_bytes();
 int split_pack(const tt_mlp_weights *w, void *ws, hipStream_t stream);
 int split_forward(bool critic, int n, const float *obs, const float *action, const tt_mlp_weights *w, float *out,
                   const ActArgs &act, hipStream_t stream);
+#ifdef TT_STAMPS
+int split_debug_stamps(unsigned long long *out16);
+#endif
 
 }  // namespace ttnet

@@ -25,6 +25,13 @@
 namespace ttnet {
 namespace {
 
+#ifdef TT_STAMPS   // diagnostic build only: clocks of workgroup 0 / thread 0 at the phase boundaries
+__device__ unsigned long long g_nstamps[16];
+#define NSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_nstamps[i] = wall_clock64(); g_nstamps[8 + i] = clock64(); } } while (0)
+#else
+#define NSTAMP(i) do { } while (0)
+#endif
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
@@ -108,20 +115,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(lane_off), "s"(src), "s"(dst) : "memory");
     };
-    auto chunk_issue = [&](const int s) {
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(w2p) + (size_t)s * CHUNK_BYTES + wave * 8192;
-        const unsigned dst = lds_base + (s % RING) * CHUNK_BYTES + wave * 8192;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(lane_off), "s"(src + i * 1024), "s"(dst + i * 1024) : "memory");
-        }
-    };
 
+    NSTAMP(0);
     // ---- prologue: k16 steps 0 and 1 of fc2 start moving; raw fc1 and the per-neuron vectors (zero-padded) -> LDS
-    chunk_issue(0);
-    chunk_issue(1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) chunk_issue_piece(i >> 3, i & 7);
     {
         const float4 *src = reinterpret_cast<const float4 *>(W.w1);           // 9200 floats = 2300 float4
         float4 *dst = reinterpret_cast<float4 *>(w1_s);
@@ -144,6 +142,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
         bx[q] = (k < IN && row < n) ? obs[(size_t)row * IN + k] : 0.f;
     }
     __syncthreads();
+    NSTAMP(1);
 
     // ---- layer 1 on the exact f32 MFMA: acc1[t][v] = pre-activation of neuron 32t + 8(v>>2) + 4h + (v&3), env `row`
     f32x16 acc1[T1];
@@ -161,6 +160,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
 #pragma unroll
         for (int q = 0; q < KQ; ++q) acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bx[q], acc1[t], 0, 0, 0);
     }
+    NSTAMP(2);
     // bias, LayerNorm(400) (biased variance, eps 1e-5), ReLU -- in place; tile 12 holds neurons 384..399 in v < 8
     {
         float s = 0.f;
@@ -192,13 +192,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
             }
     }
 
+    NSTAMP(3);
     // ---- layer 2: 25 k16 steps x 10 neuron tiles x 6 bf16 MFMAs; the h1 registers are the B operand
     f32x16 acc2[T2];
 #pragma unroll
     for (int u = 0; u < T2; ++u)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc2[u][v] = 0.f;
-#ifdef TT_SPLIT_PIPE
     // Hand-pipelined issue order, pinned with sched_barrier(0) between every pair of instructions groups: each of the
     // six MFMAs of a tile is followed by one small job that issues while the matrix pipe is busy (an MFMA holds the
     // wave's issue port for 8 of its 32 cycles) -- the three fragment reads of the NEXT tile, then in tiles 0..3 one
@@ -257,48 +257,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
             for (int q = 0; q < 4; ++q) cb[p][q] = nb[p][q];
     }
 #undef SB
-#else
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-        uint32_t bh[4], bm[4], bl[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            split2(acc1[s >> 1][8 * (s & 1) + 2 * q], acc1[s >> 1][8 * (s & 1) + 2 * q + 1], bh[q], bm[q], bl[q]);
-        const uint4 vh = make_uint4(bh[0], bh[1], bh[2], bh[3]), vm = make_uint4(bm[0], bm[1], bm[2], bm[3]),
-                    vl = make_uint4(bl[0], bl[1], bl[2], bl[3]);
-        if (s + 1 < STEPS) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's pieces of step s have landed
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (those of step s + 1 may still be in flight)
-        __syncthreads();                                  // step s is whole in slot s % 3; slot (s + 2) % 3 is free
-        if (s + 2 < STEPS) chunk_issue(s + 2);
-        const uint4 *slot = ring + (s % RING) * CHUNK_U4 + lane;
-        uint4 a[2][3];
-        a[0][0] = slot[0]; a[0][1] = slot[64]; a[0][2] = slot[128];
-#pragma unroll
-        for (int u = 0; u < T2; ++u) {
-            if (u + 1 < T2) {
-                a[(u + 1) & 1][0] = slot[((u + 1) * 3) * 64]; a[(u + 1) & 1][1] = slot[((u + 1) * 3 + 1) * 64];
-                a[(u + 1) & 1][2] = slot[((u + 1) * 3 + 2) * 64];
-            }
-#ifdef TT_SPLIT_PIN
-            __builtin_amdgcn_sched_barrier(0);            // tile u+1's fragment reads issue before tile u's MFMAs
-#else
-            asm volatile("" ::: "memory");                // keep the fragment reads one tile ahead, not ten
-#endif
-            const uint4 ah = a[u & 1][0], am = a[u & 1][1], al = a[u & 1][2];
-            acc2[u] = mfma_bf16(al, vh, acc2[u]);         // small terms first
-            acc2[u] = mfma_bf16(ah, vl, acc2[u]);
-            acc2[u] = mfma_bf16(am, vm, acc2[u]);
-            acc2[u] = mfma_bf16(am, vh, acc2[u]);
-            acc2[u] = mfma_bf16(ah, vm, acc2[u]);
-            acc2[u] = mfma_bf16(ah, vh, acc2[u]);
-#ifdef TT_SPLIT_PIN
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
-    }
 
-#endif
-
+    NSTAMP(4);
     // ---- epilogue: bias, LayerNorm(300), (critic: + action_value(a)), ReLU, head; acc2[u][v] is neuron
     // 32u + 8(v>>2) + 4h + (v&3); 300 = 9*32 + 12, so groups of four are all real or all padding
     float s2 = 0.f;
@@ -344,9 +304,16 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
         }
     const float v = dot + __shfl_xor(dot, 32) + W.b3[0];
     if (h == 0 && row < n) finish_row<CRITIC>(row, v, out, act);
+    NSTAMP(5);
 }
 
 }  // namespace
+
+#ifdef TT_STAMPS
+int split_debug_stamps(unsigned long long *out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_nstamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -3;
+}
+#endif
 
 size_t split_ws_bytes() { return (size_t)STEPS * CHUNK_BYTES; }             // 819,200 B
 

@@ -4,6 +4,7 @@ torch tensors.
 Used where no gradient is needed: the N-env `choose_action` of the rollout loop and the target-network
 forward passes of `learn()`.  Networks of other shapes (or CPU tensors) report `supported(net) == False` and the
 callers use the plain torch modules."""
+import contextlib
 import ctypes as C
 import math
 
@@ -43,6 +44,18 @@ def weights_of(net):
     w.split_ws = net._tt_split_ws.data_ptr()
     net._tt_weights = (key, w)
     return w
+
+
+@contextlib.contextmanager
+def exact_f32(net):
+    """Within the block, forwards of `net` run on the exact-f32 MFMA kernel whatever the batch (the split-bf16 kernel's
+    bit-reference; tests and A/B timing)."""
+    w = weights_of(net)
+    ws, w.split_ws = w.split_ws, None
+    try:
+        yield
+    finally:
+        w.split_ws = ws
 
 
 def _stream(t):

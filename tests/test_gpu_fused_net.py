@@ -1,5 +1,6 @@
-"""GPU (-m gpu): the fused f32-MFMA actor / critic inference kernels (csrc/ttnet.hip) against the plain
-torch modules (f32 reference of the same op), tolerance 2e-5 absolute on tanh outputs / 2e-5 relative on Q."""
+"""GPU (-m gpu): the fused actor / critic inference kernels -- exact-f32 MFMA (csrc/ttnet.hip) and, from 1024 rows,
+split-bf16 MFMA (csrc/ttnet_split.hip) -- against the plain torch modules (f32 reference of the same op), tolerance
+2e-5 absolute on tanh outputs / 2e-5 relative on Q; the two kernels against each other and against torch in f64."""
 import math
 
 import numpy as np
@@ -22,8 +23,11 @@ def _nets(dev, seed=0):
     return a, c
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 1000, 65536])
-def test_actor_and_critic_forward_match_torch(gpu_device, n):
+@pytest.mark.parametrize("n", [1, 63, 64, 1000, 1024, 1153, 65536])
+@pytest.mark.parametrize("kernel", ["default", "f32"])
+def test_actor_and_critic_forward_match_torch(gpu_device, n, kernel):
+    """default = what the launcher picks (exact f32 below 1024 rows, split-bf16 from there); f32 = exact f32 forced."""
+    import contextlib
     import torch
     from ddpg_trucktrailer_amd import fused
     actor, critic = _nets(gpu_device)
@@ -33,11 +37,36 @@ def test_actor_and_critic_forward_match_torch(gpu_device, n):
     act = torch.rand((n, 1), device=gpu_device, generator=g) * 2.4 - 1.2
     with torch.no_grad():
         ref_mu, ref_q = actor(obs), critic(obs, act)
-    mu = fused.actor_forward(actor, obs)
-    q = fused.critic_forward(critic, obs, act)
+    with (fused.exact_f32(actor) if kernel == "f32" else contextlib.nullcontext()), \
+            (fused.exact_f32(critic) if kernel == "f32" else contextlib.nullcontext()):
+        mu = fused.actor_forward(actor, obs)
+        q = fused.critic_forward(critic, obs, act)
     assert mu.shape == ref_mu.shape and q.shape == ref_q.shape
     assert (mu - ref_mu).abs().max().item() <= 2e-5
     assert (q - ref_q).abs().max().item() <= 2e-5 * max(1.0, ref_q.abs().max().item())
+
+
+def test_split_bf16_kernel_is_f32_accurate(gpu_device):
+    """The split-bf16 kernel (three exact bf16 pieces per f32 operand, 6 of the 9 partial products) against the
+    exact-f32 kernel and against the modules evaluated in f64: its error is of the size of f32 rounding itself."""
+    import torch
+    from ddpg_trucktrailer_amd import fused
+    actor, critic = _nets(gpu_device, seed=11)
+    n = 20000 + 77                                     # not a multiple of the 128-row workgroup tile
+    obs = torch.rand((n, 23), device=gpu_device) * 2 - 1
+    act = torch.rand((n, 1), device=gpu_device) * 2.4 - 1.2
+    mu_s, q_s = fused.actor_forward(actor, obs).clone(), fused.critic_forward(critic, obs, act).clone()
+    with fused.exact_f32(actor), fused.exact_f32(critic):
+        mu_e, q_e = fused.actor_forward(actor, obs).clone(), fused.critic_forward(critic, obs, act).clone()
+    assert not torch.equal(mu_s, mu_e)                 # really two kernels
+    assert (mu_s - mu_e).abs().max().item() <= 1e-5 and (q_s - q_e).abs().max().item() <= 2e-5
+    with torch.no_grad():
+        mu64 = actor.double()(obs.double()).float(); q64 = critic.double()(obs.double(), act.double()).float()
+        actor.float(); critic.float()
+        mu_t = actor(obs)
+    err_s, err_e, err_t = ((x - mu64).abs().max().item() for x in (mu_s, mu_e, mu_t))
+    assert err_s <= 3 * max(err_e, err_t) + 1e-7, (err_s, err_e, err_t)
+    assert (q_s - q64).abs().max().item() <= 3 * (q_e - q64).abs().max().item() + 1e-6
 
 
 def test_real_observations_and_weight_updates_are_seen(gpu_device):
