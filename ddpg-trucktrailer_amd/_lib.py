@@ -66,6 +66,7 @@ _SIGNATURES = {
     "tt_env_set_max_steps": (C.c_int, [_P, _P, _I, _P, _P]),
     "tt_env_get_episode": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "tt_env_observe": (C.c_int, [_P, _P, _P, _P]),
+    "tt_env_set_step_counter": (C.c_int, [_P, _P]),
     "tt_env_step": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(TTInfo), _I, _P]),
     "tt_env_step_random": (C.c_int, [_P, _U64, _P, _P, _P, _P, C.POINTER(TTInfo), _I, _P]),
     "tt_env_state_bytes": (C.c_size_t, [_P]),

@@ -150,6 +150,7 @@ struct Bufs {
     double *hot;         // [ntiles][H_ROWS][TILE]
     double *cold;        // [C_ROWS][npad]
     uint32_t *episodes;  // [npad] episode number of each env (keys the reset RNG)
+    long long *counter;  // optional caller-owned count of vector steps (tt_env_set_step_counter), advanced by k_step
 };
 
 __device__ __forceinline__ double *hot_ptr(double *hot, int i) {
@@ -629,6 +630,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(const KParams P, const int n, co
     const int nv = min(BLOCK, n - block_first);
     float of[OBS];
 
+    if (b.counter && i == 0) *b.counter += 1;      // one more vector step stored (read by later launches only)
     if (valid) {
         Env e;
         load_env<PER_ENV>(P, b, i, e);
@@ -861,7 +863,7 @@ struct tt_env {
     int n = 0, npad = 0, device = 0;
     tt_params params{};
     KParams kp{};
-    Bufs b{nullptr, nullptr, nullptr};
+    Bufs b{nullptr, nullptr, nullptr, nullptr};
     bool per_env = false;
     uint64_t seed = 0;
     // optional per-launch timing of the step kernel (tt_env_profile): event pairs bound to the dispatch
@@ -1156,6 +1158,12 @@ int tt_env_observe(tt_env *env, const float *steering, float *obs_out, tt_stream
     else
         hipLaunchKernelGGL(k_observe<false>, g, b, 0, stream, env->kp, env->n, env->b, steering, obs_out);
     TT_HIP(env, hipGetLastError());
+    return TT_OK;
+}
+
+int tt_env_set_step_counter(tt_env *env, int64_t *counter) {
+    if (!env) return fail(nullptr, TT_EINVAL, "tt_env_set_step_counter: NULL handle");
+    env->b.counter = reinterpret_cast<long long *>(counter);
     return TT_OK;
 }
 

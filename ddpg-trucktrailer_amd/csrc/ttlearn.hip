@@ -483,26 +483,6 @@ constexpr int NCAT = 10;                            // db2 dg2 dbe2 db1 dg1 dbe1
 constexpr int SUMB_ACTOR = 3 * 5 + 3 * 7 + 5 + 1;   // 64-column chunks per quantity: 300 -> 5, 400 -> 7, 1 -> 1
 constexpr int SUMB_CRITIC = SUMB_ACTOR + 2 * 5;
 
-__device__ __forceinline__ float colsum_term(const int q, const int b, const Saved &sv, const BwdOut &d,
-                                             const float *__restrict__ action) {
-    // q indexes the concatenation [db2 | dg2 | dbe2 | db1 | dg1 | dbe1 | dw3 | db3 | dwa | dba]
-    if (q < 3 * H2) {
-        const int which = q / H2, c = q - which * H2;
-        const size_t p = (size_t)b * H2 + c;
-        return which == 0 ? d.dx2[p] : (which == 1 ? d.dz[p] * sv.xh2[p] : d.dz[p]);
-    }
-    if (q < 3 * H2 + 3 * H1) {
-        const int qq = q - 3 * H2, which = qq / H1, c = qq - which * H1;
-        const size_t p = (size_t)b * H1 + c;
-        return which == 0 ? d.dx1[p] : (which == 1 ? d.dy1[p] * sv.xh1[p] : d.dy1[p]);
-    }
-    if (q < 3 * H2 + 3 * H1 + H2) return d.dpre[b] * sv.h2[(size_t)b * H2 + (q - 3 * H2 - 3 * H1)];
-    if (q == 3 * H2 + 3 * H1 + H2) return d.dpre[b];
-    const int qq = q - (3 * H2 + 3 * H1 + H2 + 1), which = qq / H2, c = qq - which * H2;
-    const float dz = d.dz[(size_t)b * H2 + c];
-    return which == 0 ? dz * action[b] : dz;
-}
-
 __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int critic, const float *__restrict__ obs,
                                                      const float *__restrict__ action, const Saved sv,
                                                      const BwdOut d, const Grads G) {
@@ -611,22 +591,48 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
         }
         const int c = cb * 64 + lane;
         const bool valid = cat >= 0 && c < base;
+        // every quantity is sum_b A[b*sa + ca] (* B[b*sb + cb]); the operands are picked ONCE per workgroup so that the
+        // row loops below are straight-line: 16 (or 32) independent loads in flight, then one add chain in row order.
+        // (A per-term switch on the quantity serialises the loads: one L2/HBM round trip per row.)
+        const float *A = nullptr, *Bp = nullptr;
+        int sa = 0, sb = 0, ca = 0, cbb = 0;
+        switch (cat) {
+            case 0: A = d.dx2; sa = H2; ca = c; break;                                   // db2
+            case 1: A = d.dz; sa = H2; ca = c; Bp = sv.xh2; sb = H2; cbb = c; break;     // dg2 = sum dz * xh2
+            case 2: A = d.dz; sa = H2; ca = c; break;                                    // dbe2
+            case 3: A = d.dx1; sa = H1; ca = c; break;                                   // db1
+            case 4: A = d.dy1; sa = H1; ca = c; Bp = sv.xh1; sb = H1; cbb = c; break;    // dg1 = sum dy1 * xh1
+            case 5: A = d.dy1; sa = H1; ca = c; break;                                   // dbe1
+            case 6: A = d.dpre; sa = 1; ca = 0; Bp = sv.h2; sb = H2; cbb = c; break;     // dw3 = sum dpre * h2
+            case 7: A = d.dpre; sa = 1; ca = 0; break;                                   // db3
+            case 8: A = d.dz; sa = H2; ca = c; Bp = action; sb = 1; cbb = 0; break;      // dwa = sum dz * a
+            case 9: A = d.dz; sa = H2; ca = c; break;                                    // dba
+            default: break;
+        }
         float acc = 0.f;
         if (valid) {
             const int rows = (n + 3) / 4, lo = wave * rows, hi = min(n, lo + rows);
-            // q in the layout colsum_term() understands
-            const int q = cat < 3 ? cat * H2 + c : (cat < 6 ? 3 * H2 + (cat - 3) * H1 + c
-                          : (cat == 6 ? 3 * H2 + 3 * H1 + c : (cat == 7 ? 3 * H2 + 3 * H1 + H2
-                          : 3 * H2 + 3 * H1 + H2 + 1 + (cat - 8) * H2 + c)));
+            const float *pa = A + ca, *pb = Bp ? Bp + cbb : nullptr;
             int b = lo;
-            for (; b + 16 <= hi; b += 16) {               // 16 independent loads in flight, then one add chain
-                float t[16];
+            if (pb) {
+                for (; b + 16 <= hi; b += 16) {
+                    float t[16], u2[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) t[u] = colsum_term(q, b + u, sv, d, action);
+                    for (int u = 0; u < 16; ++u) { t[u] = pa[(size_t)(b + u) * sa]; u2[u] = pb[(size_t)(b + u) * sb]; }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc += t[u];
+                    for (int u = 0; u < 16; ++u) acc += t[u] * u2[u];
+                }
+                for (; b < hi; ++b) acc += pa[(size_t)b * sa] * pb[(size_t)b * sb];
+            } else {
+                for (; b + 16 <= hi; b += 16) {
+                    float t[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) t[u] = pa[(size_t)(b + u) * sa];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) acc += t[u];
+                }
+                for (; b < hi; ++b) acc += pa[(size_t)b * sa];
             }
-            for (; b < hi; ++b) acc += colsum_term(q, b, sv, d, action);
         }
         part[wave][0][lane] = acc;
         __syncthreads();

@@ -64,6 +64,13 @@ class TrajectoryRing:
         self.done = torch.zeros((slots, n_envs), dtype=torch.uint8, device=device)
         self.k = 0                                                          # vector steps completed (host)
         self.k_dev = torch.zeros((), dtype=torch.int64, device=device)      # same, on the device (graph-safe)
+        self._env_counts = False                                            # True: the env's step kernel advances k_dev
+
+    def attach(self, env):
+        """Let the env's step kernel advance k_dev (tt_env_set_step_counter): one launch less per vector step.  From
+        then on every env.step()/step_random() of that env counts as one stored vector step."""
+        env.set_step_counter(self.k_dev)
+        self._env_counts = True
 
     @property
     def capacity(self):
@@ -77,10 +84,12 @@ class TrajectoryRing:
 
     def advance(self):
         self.k += 1
-        self.k_dev += 1
+        if not self._env_counts:
+            self.k_dev += 1
 
-    def sample_fused(self, batch_size, seed=0, return_index=False):
-        """sample() as ONE HIP launch (tt_ring_sample): Philox indices keyed by (seed, k_dev) + gather."""
+    def sample_fused(self, batch_size, seed=0, return_index=False, done_as_bool=True):
+        """sample() as ONE HIP launch (tt_ring_sample): Philox indices keyed by (seed, k_dev) + gather.
+        done_as_bool=False returns the raw uint8 flags (no conversion launch; what the fused learner takes)."""
         import ctypes as C
         from ddpg_trucktrailer_amd import _lib as L
         if getattr(self, "_bufs", None) is None or self._bufs[0].shape[0] != batch_size:
@@ -94,7 +103,7 @@ class TrajectoryRing:
         L.check(L.load().tt_ring_sample(batch_size, self.n, self.slots, p(self.k_dev), p(self.obs), p(self.act), p(self.rew),
                                         p(self.done), int(seed) & (2 ** 64 - 1), p(s), p(a), p(r), p(s2), p(dn), p(idx),
                                         C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
-        out = (s, a, r, s2, dn.bool())
+        out = (s, a, r, s2, dn.bool() if done_as_bool else dn)
         return out + (idx,) if return_index else out
 
     def sample(self, batch_size, generator=None):

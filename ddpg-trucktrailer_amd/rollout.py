@@ -34,6 +34,8 @@ class DDPGRollout:
         if world_size > 1:
             self.agent.enable_data_parallel()
         self.ring = TrajectoryRing(self.n, replay_slots, env.observation_dim, self.device)
+        if self.device.type == "cuda":
+            self.ring.attach(env)                          # the step kernel advances the ring's device counter
         self.noise = VecOUNoise(self.n, self.device)
         self.high = float(np.float32(math.pi / 4))       # env.action_space.high (f32 pi/4, simv2.py:86-91)
         self.scaled = torch.zeros(self.n, dtype=torch.float32, device=self.device)
@@ -70,11 +72,11 @@ class DDPGRollout:
     # -------------------------------------------------------------- learning
     def _learn_once(self):
         if self.device.type == "cuda":
-            s, a, r, s2, d = self.ring.sample_fused(self.batch_size, seed=self.seed)
+            s, a, r, s2, d = self.ring.sample_fused(self.batch_size, seed=self.seed, done_as_bool=self.learner is None)
         else:
             s, a, r, s2, d = self.ring.sample(self.batch_size)
         if self.learner is not None:
-            self.learner.learn_batch(s, a, r, s2, self.ring._bufs[4])     # raw uint8 done flags of the sample
+            self.learner.learn_batch(s, a, r, s2, d)                      # raw uint8 done flags of the sample
         else:
             self.agent.learn_batch(s, a, r, s2, d)
 

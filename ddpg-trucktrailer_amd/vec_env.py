@@ -186,6 +186,14 @@ class TruckTrailerVecEnv:
                                          C.byref(ti) if ti is not None else None, 1 if auto_reset else 0, self._stream()))
         return obs, rew, done, inf
 
+    def set_step_counter(self, counter):
+        """counter: device int64 scalar tensor that every step launch advances by 1 (None detaches); see
+        include/ttenv.h: tt_env_set_step_counter.  The tensor is kept alive by this object."""
+        if counter is not None:
+            assert counter.dtype == torch.int64 and counter.device == self.device and counter.numel() == 1
+        self._step_counter = counter
+        self._check(self.lib.tt_env_set_step_counter(self._h, _ptr(counter) if counter is not None else None))
+
     def step_random(self, policy_seed=123, auto_reset=True, info=False, action_out=None, obs_out=None, reward_out=None,
                     done_out=None):
         """step() with the random policy of BASELINE.json config 2 drawn inside the kernel (graph-capturable)."""

@@ -147,6 +147,11 @@ int tt_env_observe(tt_env *env, const float *steering, float *obs_out, tt_stream
  * auto_reset != 0: an env that is done is re-placed like tt_env_reset (its obs row is then the
  * fresh episode's first observation; reward/done/info still describe the finished step).  The
  * reference never resets by itself (trainv2.py:489); auto_reset = 0 reproduces that. */
+/* Optional device-side count of vector steps: every tt_env_step / tt_env_step_random launch adds 1 to *counter
+ * (device int64, caller-owned; NULL detaches).  The trajectory ring's sampler (tt_ring_sample: k_dev) reads it, so a
+ * vector step needs no separate launch to advance the ring. */
+int tt_env_set_step_counter(tt_env *env, int64_t *counter);
+
 int tt_env_step(tt_env *env, const float *action, float *obs, float *reward, uint8_t *done, const tt_info *info,
                 int auto_reset, tt_stream_t stream);
 
