@@ -34,7 +34,9 @@ def parse():
     ap.add_argument("--replay-slots", type=int, default=64, help="ring length in vector steps (capacity = slots*N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-graph", action="store_true", help="run learn() eagerly instead of as a hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="launch everything eagerly (no hipGraphs)")
+    ap.add_argument("--step-graph", type=int, default=4, help="ddpg workload: whole vector steps per captured hipGraph "
+                    "(0: only learn() is captured)")
     ap.add_argument("--torch-learn", action="store_true", help="learn() through torch autograd instead of the fused HIP kernels")
     ap.add_argument("--graph-steps", type=int, default=50, help="env workload: vector steps per captured hipGraph")
     return ap.parse_args()
@@ -149,6 +151,7 @@ def main():
     env.reset(seed=27 + rank)
 
     graph_k = 1
+    ddpg_loop = None
     if args.workload == "env":
         # one vector step = one launch of the fused kernel (action drawn in-kernel).  Launch-bound in eager
         # Python at this N, so G steps are captured into one hipGraph and a "step" replays 1/G of it.
@@ -178,15 +181,22 @@ def main():
     else:
         from ddpg_trucktrailer_amd.rollout import DDPGRollout
         loop = DDPGRollout(env, batch_size=args.batch, replay_slots=args.replay_slots, seed=27 + rank,
-                           world_size=world, use_graph=not args.no_graph, fused_learn=not args.torch_learn)
+                           world_size=world, use_graph=not args.no_graph, fused_learn=not args.torch_learn,
+                           graph_steps=args.step_graph)
 
         def one_step(timed):
             loop.step()
+        ddpg_loop = loop
         workload = (f"simv2 N={n}/GPU + full DDPG learn() per vector step (actor/critic 400x300, batch {args.batch}, "
                     f"OU noise, replay ring {args.replay_slots}xN) (BASELINE config 3)")
-        extra = {"batch": args.batch, "replay_capacity": args.replay_slots * n}
+        extra = {"batch": args.batch, "replay_capacity": args.replay_slots * n,
+                 "launch": (f"hipGraphs of {loop.graph_steps} whole vector steps" if loop.graph_steps else
+                            ("eager, learn() as a hipGraph" if loop.use_graph else "eager"))}
 
     def run(k_steps, timed):
+        if ddpg_loop is not None:
+            ddpg_loop.run(k_steps)       # hipGraphs of whole vector steps (policy + env step + learn), eager remainder
+            return
         for _ in range(k_steps // graph_k):
             one_step(timed)
 
@@ -194,7 +204,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if graph_k == 1:
+    captured = graph_k > 1 or (ddpg_loop is not None and ddpg_loop.graph_steps > 0)
+    if not captured:
         env.profile(args.steps)      # per-dispatch HIP events on the step kernel, inside the timed region
     t0 = time.perf_counter()
     run(args.steps, True)
@@ -207,12 +218,15 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if graph_k > 1:
-        # a captured launch cannot carry its own events: time the same kernel on the same state right after,
-        # eagerly, with the per-dispatch events (the timed region above is untouched by this)
+    if captured:
+        # a captured launch cannot carry its own events: time the same kernel in the same loop on the same state right
+        # after, eagerly, with the per-dispatch events (the timed region above is untouched by this)
         env.profile(min(args.steps, 2000))
         for _ in range(min(args.steps, 2000)):
-            env.step_random(123 + rank, auto_reset=True)
+            if ddpg_loop is not None:
+                ddpg_loop.step()
+            else:
+                env.step_random(123 + rank, auto_reset=True)
     kern_total_ms, kern_launches = env.profile_read()
     env.profile(0)
     kern_ms = kern_total_ms / max(1, kern_launches)

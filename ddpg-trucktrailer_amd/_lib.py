@@ -41,6 +41,12 @@ class TTMlpSaved(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("xh1", "h1", "xh2", "h2", "rstd1", "rstd2")]
 
 
+class TTFwdJob(C.Structure):
+    _fields_ = [("critic", C.c_int32), ("reserved_", C.c_int32), ("obs", C.c_void_p), ("action", C.c_void_p),
+                ("w", C.POINTER(TTMlpWeights)), ("out", C.c_void_p), ("saved", C.POINTER(TTMlpSaved)),
+                ("dq_da", C.c_void_p), ("z_state", C.c_void_p)]
+
+
 class TTMlpBwdWs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dpre", "dz", "dx2", "dy1", "dx1")]
 
@@ -82,8 +88,14 @@ _SIGNATURES = {
     "tt_ring_sample": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _U64, _P, _P, _P, _P, _P, _P, _P]),
     "tt_critic_forward": (C.c_int, [_I, _P, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_mlp_forward_save": (C.c_int, [_I, _I, _P, _P, C.POINTER(TTMlpWeights), _P, C.POINTER(TTMlpSaved), _P, _P]),
+    "tt_mlp_forward_multi": (C.c_int, [_I, _I, C.POINTER(TTFwdJob), _P]),
+    "tt_critic_state_forward": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P]),
+    "tt_critic_head_td": (C.c_int, [_I, _P, _P, C.POINTER(TTMlpWeights), _P, _P, C.c_float, _P, _P, _P, _P]),
     "tt_mlp_backward": (C.c_int, [_I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, C.POINTER(TTMlpWeights),
                                   C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights), _P]),
+    "tt_mlp_backward_adam": (C.c_int, [_I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, C.POINTER(TTMlpWeights),
+                                       C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights), _I, _P, _P, _P,
+                                       _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "tt_adam_soft_update": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                       C.c_float, C.c_float, _P]),
     "tt_td_target": (C.c_int, [_I, _P, _P, _P, C.c_float, _P, _P, _P]),

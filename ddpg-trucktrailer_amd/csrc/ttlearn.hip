@@ -96,13 +96,13 @@ __device__ __forceinline__ void cross_wave_sum(float *red, int wave, int l4, int
 // waves_per_eu(1,1): tell the scheduler NOT to trade the deep load pipelining for occupancy it cannot use anyway
 // (16 workgroups on 256 CUs); without it hipcc keeps ~60 VGPRs and issues the weight loads a few at a time
 template <bool CRITIC>
-__global__ __launch_bounds__(64 * NW) void k_fwd_small(const int n, const float *__restrict__ obs,
-                                                   const float *__restrict__ action, const Weights W,
-                                                   float *__restrict__ out, const Saved sv, float *__restrict__ dq_da) {
-    __shared__ __attribute__((aligned(16))) float h1_s[TR * HS1];     // [16][404]: A operand of layer 2
-    __shared__ float red[NW * TR];
+__device__ __forceinline__ void fwd_small_body(const int n, const float *__restrict__ obs,
+                                               const float *__restrict__ action, const Weights &W,
+                                               float *__restrict__ out, const Saved &sv, float *__restrict__ dq_da,
+                                               float *__restrict__ z_state, float *__restrict__ h1_s,
+                                               float *__restrict__ red, const int row0) {
+    // h1_s [16][404]: A operand of layer 2; red [NW][16]: cross-wave reductions
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-    const int row0 = blockIdx.x * TR;
 
     STAMP(0);
     // ---- layer 1 (K = 23): operands straight from global; this wave's column tiles t = wave, wave+NW, ...
@@ -258,6 +258,23 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_small(const int n, const float 
             if (row0 + l4 * 4 + r < n) sv.rstd2[row0 + l4 * 4 + r] = rstd[r];
     }
     float av[4] = {0.f, 0.f, 0.f, 0.f};
+    if (CRITIC && z_state) {
+        // state branch only (networks.py:55-61): z_state [B,300] = bn2(fc2(relu(bn1(fc1(s))))) before the action enters;
+        // k_head_td finishes q once the action is known, so this pass can run NEXT TO the actor pass that produces it
+#pragma unroll
+        for (int i = 0; i < MT2; ++i) {
+            const int col = (wave + NW * i) * 16 + l15;
+            if (wave + NW * i < NT2 && col < H2) {
+                const float g = W.g2[col], be = W.be2[col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + l4 * 4 + r;
+                    if (row < n) z_state[(size_t)row * H2 + col] = fmaf((acc2[i][r] - mean[r]) * rstd[r], g, be);
+                }
+            }
+        }
+        return;
+    }
     if (CRITIC) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -310,6 +327,41 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_small(const int n, const float 
         }
     }
     STAMP(4);
+}
+
+template <bool CRITIC>
+__global__ __launch_bounds__(64 * NW) void k_fwd_small(const int n, const float *__restrict__ obs,
+                                                   const float *__restrict__ action, const Weights W,
+                                                   float *__restrict__ out, const Saved sv, float *__restrict__ dq_da,
+                                                   float *__restrict__ z_state) {
+    __shared__ __attribute__((aligned(16))) float h1_s[TR * HS1];
+    __shared__ float red[NW * TR];
+    fwd_small_body<CRITIC>(n, obs, action, W, out, sv, dq_da, z_state, h1_s, red, blockIdx.x * TR);
+}
+
+// Up to four independent forwards on the same number of rows in ONE launch (workgroup b serves job b / blocks_per_job):
+// learn()'s first phase -- target actor on s', the target critic's state branch on s', Q(s,a) and mu(s) -- needs no
+// stream fork/join inside the captured graph this way (each fork costs 10-20 us of cross-queue signalling, as much as
+// the kernel it would hide).
+struct FwdJob {
+    const float *obs, *action;
+    Weights W;
+    float *out;
+    Saved sv;
+    float *dq_da, *z_state;
+    int critic;
+};
+struct FwdJobs {
+    FwdJob j[4];
+    int n, blocks_per_job;
+};
+__global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
+    __shared__ __attribute__((aligned(16))) float h1_s[TR * HS1];
+    __shared__ float red[NW * TR];
+    const int job = blockIdx.x / J.blocks_per_job, row0 = (blockIdx.x - job * J.blocks_per_job) * TR;
+    const FwdJob &q = J.j[job];
+    if (q.critic) fwd_small_body<true>(J.n, q.obs, q.action, q.W, q.out, q.sv, q.dq_da, q.z_state, h1_s, red, row0);
+    else fwd_small_body<false>(J.n, q.obs, q.action, q.W, q.out, q.sv, nullptr, nullptr, h1_s, red, row0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -472,6 +524,35 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows(const int n, const int mod
 //   [NU2, NU2+NU1)      dW1 [400,23]  = dX1^T * S : 16 rows j x 2 column tiles per workgroup; 25
 //   then                column sums (db2, dg2, dbe2, db1, dg1, dbe1, dw3, db3, critic: dwa, dba): a workgroup sums 64
 //                       columns, its 4 waves a quarter of the rows each
+// Optional optimizer step inside k_bwd_weights: the workgroup that finishes a gradient element owns it (K = batch is
+// never split across workgroups), so it can apply torch.optim.Adam and the soft target update to that element right
+// away -- the arithmetic of k_adam_soft below, one launch and one pass over the gradient less per network.  Not used
+// when the gradients are all-reduced across ranks first.  Tensor order: w1 b1 g1 be1 w2 b2 g2 be2 w3 b3 wa ba.
+struct AdamFused {
+    float *p[12], *m[12], *v[12], *tgt[12];
+    const long long *step_dev;
+    float lr, beta1, beta2, eps, weight_decay, tau;
+    int on;
+};
+struct AdamCoef { float step_size, rsqrt_bc2; };      // lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) as k_adam_soft forms them
+
+__device__ __forceinline__ void adam_apply(const AdamFused &A, const int t, const size_t i, const float grad,
+                                           const float bc1, const float sqrt_bc2) {
+    float p = A.p[t][i];
+    const float g = fmaf(A.weight_decay, p, grad);
+    const float m = fmaf(A.beta1, A.m[t][i], (1.f - A.beta1) * g);
+    const float v = fmaf(A.beta2, A.v[t][i], (1.f - A.beta2) * g * g);
+    A.m[t][i] = m;
+    A.v[t][i] = v;
+    const float denom = sqrtf(v) / sqrt_bc2 + A.eps;
+    p -= (A.lr / bc1) * (m / denom);
+    A.p[t][i] = p;
+    if (A.tgt[t]) {
+        const float tg = A.tgt[t][i];
+        A.tgt[t][i] = fmaf(A.tau, p - tg, tg);
+    }
+}
+
 struct Grads {
     float *__restrict__ w1, *__restrict__ b1, *__restrict__ g1, *__restrict__ be1, *__restrict__ w2, *__restrict__ b2,
         *__restrict__ g2, *__restrict__ be2, *__restrict__ w3, *__restrict__ b3, *__restrict__ wa, *__restrict__ ba;
@@ -485,10 +566,16 @@ constexpr int SUMB_CRITIC = SUMB_ACTOR + 2 * 5;
 
 __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int critic, const float *__restrict__ obs,
                                                      const float *__restrict__ action, const Saved sv,
-                                                     const BwdOut d, const Grads G) {
+                                                     const BwdOut d, const Grads G, const AdamFused A) {
     __shared__ __attribute__((aligned(16))) float part[4][4][256];     // [wave][tile][lane*4 + r]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int blk = blockIdx.x;
+    float bc1 = 1.f, sqrt_bc2 = 1.f;
+    if (A.on) {
+        const double t = (double)*A.step_dev;
+        bc1 = (float)(1.0 - pow((double)A.beta1, t));
+        sqrt_bc2 = sqrtf((float)(1.0 - pow((double)A.beta2, t)));
+    }
     STAMPB(12, 0); STAMPB(14, NU2); STAMPB(5, NU2 + NU1);
 #ifdef TT_STAMPS
     if (threadIdx.x == 0) g_blk[blockIdx.x][0] = wall_clock64();
@@ -533,7 +620,11 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int jr = jt * 16 + l4 * 4 + r;
-                if (jr < H2) G.w2[(size_t)jr * H1 + col] = ((p0[r] + p1[r]) + p2[r]) + p3[r];
+                if (jr < H2) {
+                    const float g = ((p0[r] + p1[r]) + p2[r]) + p3[r];
+                    G.w2[(size_t)jr * H1 + col] = g;
+                    if (A.on) adam_apply(A, 4, (size_t)jr * H1 + col, g, bc1, sqrt_bc2);
+                }
             }
         }
         STAMPB(13, 0);
@@ -565,10 +656,12 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
             const int col = wave * 16 + l15;
             if (col < IN) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    G.w1[(size_t)(jt * 16 + l4 * 4 + r) * IN + col] =
-                        ((part[0][wave][lane * 4 + r] + part[1][wave][lane * 4 + r]) + part[2][wave][lane * 4 + r]) +
-                        part[3][wave][lane * 4 + r];
+                for (int r = 0; r < 4; ++r) {
+                    const float g = ((part[0][wave][lane * 4 + r] + part[1][wave][lane * 4 + r]) + part[2][wave][lane * 4 + r]) +
+                                    part[3][wave][lane * 4 + r];
+                    G.w1[(size_t)(jt * 16 + l4 * 4 + r) * IN + col] = g;
+                    if (A.on) adam_apply(A, 0, (size_t)(jt * 16 + l4 * 4 + r) * IN + col, g, bc1, sqrt_bc2);
+                }
             }
         }
         STAMPB(15, NU2);
@@ -594,25 +687,25 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
         // every quantity is sum_b A[b*sa + ca] (* B[b*sb + cb]); the operands are picked ONCE per workgroup so that the
         // row loops below are straight-line: 16 (or 32) independent loads in flight, then one add chain in row order.
         // (A per-term switch on the quantity serialises the loads: one L2/HBM round trip per row.)
-        const float *A = nullptr, *Bp = nullptr;
+        const float *Ap = nullptr, *Bp = nullptr;
         int sa = 0, sb = 0, ca = 0, cbb = 0;
         switch (cat) {
-            case 0: A = d.dx2; sa = H2; ca = c; break;                                   // db2
-            case 1: A = d.dz; sa = H2; ca = c; Bp = sv.xh2; sb = H2; cbb = c; break;     // dg2 = sum dz * xh2
-            case 2: A = d.dz; sa = H2; ca = c; break;                                    // dbe2
-            case 3: A = d.dx1; sa = H1; ca = c; break;                                   // db1
-            case 4: A = d.dy1; sa = H1; ca = c; Bp = sv.xh1; sb = H1; cbb = c; break;    // dg1 = sum dy1 * xh1
-            case 5: A = d.dy1; sa = H1; ca = c; break;                                   // dbe1
-            case 6: A = d.dpre; sa = 1; ca = 0; Bp = sv.h2; sb = H2; cbb = c; break;     // dw3 = sum dpre * h2
-            case 7: A = d.dpre; sa = 1; ca = 0; break;                                   // db3
-            case 8: A = d.dz; sa = H2; ca = c; Bp = action; sb = 1; cbb = 0; break;      // dwa = sum dz * a
-            case 9: A = d.dz; sa = H2; ca = c; break;                                    // dba
+            case 0: Ap = d.dx2; sa = H2; ca = c; break;                                   // db2
+            case 1: Ap = d.dz; sa = H2; ca = c; Bp = sv.xh2; sb = H2; cbb = c; break;     // dg2 = sum dz * xh2
+            case 2: Ap = d.dz; sa = H2; ca = c; break;                                    // dbe2
+            case 3: Ap = d.dx1; sa = H1; ca = c; break;                                   // db1
+            case 4: Ap = d.dy1; sa = H1; ca = c; Bp = sv.xh1; sb = H1; cbb = c; break;    // dg1 = sum dy1 * xh1
+            case 5: Ap = d.dy1; sa = H1; ca = c; break;                                   // dbe1
+            case 6: Ap = d.dpre; sa = 1; ca = 0; Bp = sv.h2; sb = H2; cbb = c; break;     // dw3 = sum dpre * h2
+            case 7: Ap = d.dpre; sa = 1; ca = 0; break;                                   // db3
+            case 8: Ap = d.dz; sa = H2; ca = c; Bp = action; sb = 1; cbb = 0; break;      // dwa = sum dz * a
+            case 9: Ap = d.dz; sa = H2; ca = c; break;                                    // dba
             default: break;
         }
         float acc = 0.f;
         if (valid) {
             const int rows = (n + 3) / 4, lo = wave * rows, hi = min(n, lo + rows);
-            const float *pa = A + ca, *pb = Bp ? Bp + cbb : nullptr;
+            const float *pa = Ap + ca, *pb = Bp ? Bp + cbb : nullptr;
             int b = lo;
             if (pb) {
                 for (; b + 16 <= hi; b += 16) {
@@ -640,6 +733,10 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
             const float total = ((part[0][0][lane] + part[1][0][lane]) + part[2][0][lane]) + part[3][0][lane];
             float *const outs[NCAT] = {G.b2, G.g2, G.be2, G.b1, G.g1, G.be1, G.w3, G.b3, G.wa, G.ba};
             outs[cat][c] = total;
+            if (A.on) {
+                const int tensor[NCAT] = {5, 6, 7, 1, 2, 3, 8, 9, 10, 11};
+                adam_apply(A, tensor[cat], (size_t)c, total, bc1, sqrt_bc2);
+            }
         }
         STAMPB(6, NU2 + NU1);
 #ifdef TT_STAMPS
@@ -693,6 +790,38 @@ __global__ void k_td_target(const int n, const float *__restrict__ r, const floa
     if (i < n) y[i] = done[i] ? r[i] : fmaf(gamma, q_next[i], r[i]);
 }
 
+// the rest of the critic once the action is known (networks.py:62-68) and the TD target (DDPG_agent.py:89-93) in one
+// launch: q'[b] = q(relu(z_state[b] + action_value(a[b]))), y[b] = r[b] + gamma * q'[b] * (1 - done[b]).  16 lanes per row.
+__global__ __launch_bounds__(256) void k_head_td(const int n, const float *__restrict__ z_state,
+                                                 const float *__restrict__ action, const Weights W,
+                                                 const float *__restrict__ r, const uint8_t *__restrict__ done,
+                                                 const float gamma, float *__restrict__ y, float *__restrict__ q_out,
+                                                 long long *__restrict__ step_dev) {
+    const int tid = threadIdx.x, l15 = tid & 15, row = blockIdx.x * 16 + (tid >> 4);
+    if (blockIdx.x == 0 && tid == 0 && step_dev) *step_dev += 1;
+    const bool ok = row < n;
+    const float a = ok ? action[row] : 0.f;
+    float dot = 0.f;
+    if (ok) {
+        float z[19], wa[19], ba[19], w3[19];
+#pragma unroll
+        for (int i = 0; i < 19; ++i) {
+            const int col = l15 + 16 * i;
+            const bool real = col < H2;
+            z[i] = real ? z_state[(size_t)row * H2 + col] : 0.f;
+            wa[i] = real ? W.wa[col] : 0.f; ba[i] = real ? W.ba[col] : 0.f; w3[i] = real ? W.w3[col] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 19; ++i) dot = fmaf(fmaxf(z[i] + fmaf(a, wa[i], ba[i]), 0.f), w3[i], dot);
+    }
+    dot = row_sum16(dot);
+    if (ok && l15 == 0) {
+        const float q = dot + W.b3[0];
+        if (q_out) q_out[row] = q;
+        y[row] = done[row] ? r[row] : fmaf(gamma, q, r[row]);
+    }
+}
+
 Weights to_weights(const tt_mlp_weights *w) {
     return Weights{w->w1, w->b1, w->g1, w->be1, w->w2, w->b2, w->g2, w->be2, w->w3, w->b3, w->wa, w->ba};
 }
@@ -717,15 +846,58 @@ int tt_mlp_forward_save(int n, int critic, const float *obs, const float *action
     }
     const dim3 grid((n + TR - 1) / TR), block(64 * NW);
     if (critic)
-        hipLaunchKernelGGL(k_fwd_small<true>, grid, block, 0, stream, n, obs, action, to_weights(w), out, sv, dq_da);
+        hipLaunchKernelGGL(k_fwd_small<true>, grid, block, 0, stream, n, obs, action, to_weights(w), out, sv, dq_da,
+                           static_cast<float *>(nullptr));
     else
-        hipLaunchKernelGGL(k_fwd_small<false>, grid, block, 0, stream, n, obs, action, to_weights(w), out, sv, nullptr);
+        hipLaunchKernelGGL(k_fwd_small<false>, grid, block, 0, stream, n, obs, action, to_weights(w), out, sv,
+                           static_cast<float *>(nullptr), static_cast<float *>(nullptr));
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 
-int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
-                    const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
-                    const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, tt_stream_t stream) {
+int tt_mlp_forward_multi(int n, int count, const tt_fwd_job *jobs, tt_stream_t stream) {
+    if (n < 0 || count < 1 || count > 4 || !jobs) return TT_EINVAL;
+    if (n == 0) return TT_OK;
+    FwdJobs J{};
+    J.n = n;
+    J.blocks_per_job = (n + TR - 1) / TR;
+    for (int i = 0; i < count; ++i) {
+        const tt_fwd_job &q = jobs[i];
+        const bool critic = q.critic != 0;
+        if (!q.obs || !ok_shape(q.w, critic) || (critic && !q.action && !q.z_state) || (!q.out && !q.z_state)) return TT_EINVAL;
+        Saved sv{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (q.saved) {
+            const tt_mlp_saved *p = q.saved;
+            if (!p->xh1 || !p->h1 || !p->xh2 || !p->h2 || !p->rstd1 || !p->rstd2) return TT_EINVAL;
+            sv = Saved{p->xh1, p->h1, p->xh2, p->h2, p->rstd1, p->rstd2};
+        }
+        J.j[i] = FwdJob{q.obs, q.action, to_weights(q.w), q.out, sv, q.dq_da, critic ? q.z_state : nullptr, critic ? 1 : 0};
+    }
+    hipLaunchKernelGGL(k_fwd_multi, dim3(count * J.blocks_per_job), dim3(64 * NW), 0, stream, J);
+    return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+int tt_critic_state_forward(int n, const float *obs, const tt_mlp_weights *w, float *z_state, tt_stream_t stream) {
+    if (n < 0 || !obs || !z_state || !ok_shape(w, true)) return TT_EINVAL;
+    if (n == 0) return TT_OK;
+    const Saved sv{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(k_fwd_small<true>, dim3((n + TR - 1) / TR), dim3(64 * NW), 0, stream, n, obs,
+                       static_cast<const float *>(nullptr), to_weights(w), static_cast<float *>(nullptr), sv,
+                       static_cast<float *>(nullptr), z_state);
+    return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+int tt_critic_head_td(int n, const float *z_state, const float *action, const tt_mlp_weights *w, const float *reward,
+                      const uint8_t *done, float gamma, float *y, float *q_out, int64_t *step_dev, tt_stream_t stream) {
+    if (n <= 0 || !z_state || !action || !ok_shape(w, true) || !reward || !done || !y) return TT_EINVAL;
+    hipLaunchKernelGGL(k_head_td, dim3((n + 15) / 16), dim3(256), 0, stream, n, z_state, action, to_weights(w), reward, done,
+                       gamma, y, q_out, reinterpret_cast<long long *>(step_dev));
+    return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+static int backward_impl(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
+                         const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
+                         const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const AdamFused &A,
+                         tt_stream_t stream) {
     if (n <= 0 || !obs || !out || !ok_shape(w, critic != 0) || !ok_shape(grads, critic != 0) || !saved || !ws ||
         (critic && !action) || mode < 0 || mode > 2 || (mode == 0 && !d_out) || (mode == 1 && !y) || (mode == 2 && !aux))
         return TT_EINVAL;
@@ -747,8 +919,33 @@ int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, 
                   const_cast<float *>(grads->g2), const_cast<float *>(grads->be2), const_cast<float *>(grads->w3),
                   const_cast<float *>(grads->b3), const_cast<float *>(grads->wa), const_cast<float *>(grads->ba)};
     const int sum_blocks = critic ? SUMB_CRITIC : SUMB_ACTOR;
-    hipLaunchKernelGGL(k_bwd_weights, dim3(NU2 + NU1 + sum_blocks), block, 0, stream, n, critic, obs, action, sv, o, G);
+    hipLaunchKernelGGL(k_bwd_weights, dim3(NU2 + NU1 + sum_blocks), block, 0, stream, n, critic, obs, action, sv, o, G, A);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
+                    const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
+                    const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, tt_stream_t stream) {
+    AdamFused A{};
+    return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, stream);
+}
+
+int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
+                         const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
+                         const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, int count,
+                         float *const *params, float *const *exp_avg, float *const *exp_avg_sq, float *const *targets,
+                         const int64_t *step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         float tau, tt_stream_t stream) {
+    if (count != (critic ? 12 : 10) || !params || !exp_avg || !exp_avg_sq || !step_dev) return TT_EINVAL;
+    AdamFused A{};
+    for (int i = 0; i < count; ++i) {
+        if (!params[i] || !exp_avg[i] || !exp_avg_sq[i]) return TT_EINVAL;
+        A.p[i] = params[i]; A.m[i] = exp_avg[i]; A.v[i] = exp_avg_sq[i]; A.tgt[i] = targets ? targets[i] : nullptr;
+    }
+    A.step_dev = reinterpret_cast<const long long *>(step_dev);
+    A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.weight_decay = weight_decay; A.tau = tau;
+    A.on = 1;
+    return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, stream);
 }
 
 int tt_adam_soft_update(int count, float *const *params, const float *const *grads, float *const *exp_avg,

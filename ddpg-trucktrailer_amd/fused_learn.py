@@ -78,7 +78,7 @@ class FusedLearner:
         self.ws = L.TTMlpBwdWs(**{k: v.data_ptr() for k, v in self.ws_t.items()})
         self.mu_t, self.q_t, self.y, self.q, self.mu, self.q_pi, self.dq_da = (torch.empty(B, **f) for _ in range(7))
         self.step_dev = torch.zeros((), dtype=torch.int64, device=dev)      # learn() calls done (Adam's step count)
-        self.side = torch.cuda.Stream(device=dev)      # the two forwards that do not depend on the TD target run here
+        self.z_t = torch.empty((B, 300), **f)          # the target critic's state branch on s' (before the action enters)
         self.grad_sync_critic = self.grad_sync_actor = None
         ga, gc = agent.actor.optimizer.param_groups[0], agent.critic.optimizer.param_groups[0]
         self.hyp_actor = (ga["lr"], ga["betas"][0], ga["betas"][1], ga["eps"], ga["weight_decay"])
@@ -97,6 +97,15 @@ class FusedLearner:
         L.check(self.lib.tt_mlp_backward(self.B, 1 if st.critic else 0, mode, float(scale), _p(obs), _p(action), None,
                                          _p(out), _p(y), _p(aux), C.byref(fused.weights_of(st.net)), C.byref(st.saved),
                                          C.byref(self.ws), C.byref(st.gstruct), self._stream()))
+
+    def _bwd_adam(self, st, hyp, tau, mode, scale, obs, action, out, y=None, aux=None):
+        """_bwd + _adam in the backward's own two launches (include/ttenv.h: tt_mlp_backward_adam)."""
+        lr, b1, b2, eps, wd = hyp
+        L.check(self.lib.tt_mlp_backward_adam(self.B, 1 if st.critic else 0, mode, float(scale), _p(obs), _p(action), None,
+                                              _p(out), _p(y), _p(aux), C.byref(fused.weights_of(st.net)),
+                                              C.byref(st.saved), C.byref(self.ws), C.byref(st.gstruct), st.count, st.a_p,
+                                              st.a_m, st.a_v, st.a_t, _p(self.step_dev), lr, b1, b2, eps, wd, tau,
+                                              self._stream()))
 
     def _adam(self, st, hyp, tau):
         lr, b1, b2, eps, wd = hyp
@@ -118,30 +127,42 @@ class FusedLearner:
         """states, states_ [B,23] f32; actions [B,1] f32; rewards [B] f32; done_u8 [B] uint8 -- all contiguous."""
         ag, B = self.agent, self.B
         assert states.shape[0] == B and done_u8.dtype == torch.uint8
-        # Q(s,a) (DDPG_agent.py:87) and mu(s) (:101) need neither the TD target nor the critic update, so they run
-        # on a side stream next to the target-network passes (each of these kernels fills only 16 of the 256 CUs)
-        main = torch.cuda.current_stream(self.dev)
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            self._fwd(ag.critic, states, actions, self.q, self.critic.saved)
-            self._fwd(ag.actor, states, None, self.mu, self.actor.saved)
-        # targets (DDPG_agent.py:85-93)
-        self._fwd(ag.target_actor, states_, None, self.mu_t)
-        self._fwd(ag.target_critic, states_, self.mu_t, self.q_t)
-        L.check(self.lib.tt_td_target(B, _p(rewards), _p(self.q_t), _p(done_u8), float(ag.gamma), _p(self.y),
-                                      _p(self.step_dev), self._stream()))
-        main.wait_stream(self.side)
+        # DDPG_agent.py:85-93 and :87, :101.  Only the target critic's LAST step needs the target actor's action (it enters
+        # after LayerNorm2, networks.py:62-66), so four passes run side by side -- target actor on s', the target critic's
+        # state branch on s', Q(s,a), mu(s), each filling 16 of the 256 CUs -- and one small launch then finishes
+        # q'(s', mu'(s')) and the TD target.  The four are ONE launch (tt_mlp_forward_multi): a stream fork/join inside
+        # the captured graph costs more than the kernel it would hide
+        def ptr(t):
+            return None if t is None else t.data_ptr()
+        jobs = (L.TTFwdJob * 4)()
+        for j, (net, crit, obs, act, out, saved, zst) in enumerate((
+                (ag.target_actor, 0, states_, None, self.mu_t, None, None),
+                (ag.target_critic, 1, states_, None, None, None, self.z_t),
+                (ag.critic, 1, states, actions, self.q, self.critic.saved, None),
+                (ag.actor, 0, states, None, self.mu, self.actor.saved, None))):
+            jobs[j].critic, jobs[j].obs, jobs[j].action = crit, ptr(obs), ptr(act)
+            jobs[j].w, jobs[j].out = C.pointer(fused.weights_of(net)), ptr(out)
+            jobs[j].saved = C.pointer(saved) if saved is not None else None
+            jobs[j].dq_da, jobs[j].z_state = None, ptr(zst)
+        L.check(self.lib.tt_mlp_forward_multi(B, 4, jobs, self._stream()))
+        L.check(self.lib.tt_critic_head_td(B, _p(self.z_t), _p(self.mu_t), C.byref(fused.weights_of(ag.target_critic)),
+                                           _p(rewards), _p(done_u8), float(ag.gamma), _p(self.y), _p(self.q_t),
+                                           _p(self.step_dev), self._stream()))
         # critic step (DDPG_agent.py:95-98)
-        self._bwd(self.critic, 1, 2.0 / B, states, actions, self.q, y=self.y)
-        if self.grad_sync_critic is not None:
+        if self.grad_sync_critic is None:
+            self._bwd_adam(self.critic, self.hyp_critic, ag.tau, 1, 2.0 / B, states, actions, self.q, y=self.y)
+        else:
+            self._bwd(self.critic, 1, 2.0 / B, states, actions, self.q, y=self.y)
             self.grad_sync_critic()
-        self._adam(self.critic, self.hyp_critic, ag.tau)
+            self._adam(self.critic, self.hyp_critic, ag.tau)
         # actor step through the UPDATED critic (DDPG_agent.py:100-104)
         self._fwd(ag.critic, states, self.mu, self.q_pi, None, self.dq_da)
-        self._bwd(self.actor, 2, -1.0 / B, states, None, self.mu, aux=self.dq_da)
-        if self.grad_sync_actor is not None:
+        if self.grad_sync_actor is None:
+            self._bwd_adam(self.actor, self.hyp_actor, ag.tau, 2, -1.0 / B, states, None, self.mu, aux=self.dq_da)
+        else:
+            self._bwd(self.actor, 2, -1.0 / B, states, None, self.mu, aux=self.dq_da)
             self.grad_sync_actor()
-        self._adam(self.actor, self.hyp_actor, ag.tau)
+            self._adam(self.actor, self.hyp_actor, ag.tau)
 
     # ---- checkpoint interoperability with the torch optimizers ------------------------------------------
     def export_to_optimizers(self):

@@ -7,7 +7,9 @@ Per vector step, for all N envs of this rank at once:
     remember(obs, a, r, obs', done)                (a = the UNCLIPPED noisy action, trainv2.py:525):
                                                    obs', r, done are written by the kernel straight into the ring
     learn()                                        (one gradient step, batch from the ring)
-Everything stays on the device; learn() is captured into a hipGraph (sampling included)."""
+Everything stays on the device.  run(k) replays hipGraphs of `graph_steps` WHOLE vector steps (policy, env step and
+learn(): about ten launches per step, back to back with no host in between); step() is the same vector step launched
+eagerly, with learn() alone captured (sampling included).  Both give the same bits."""
 import math
 
 import numpy as np
@@ -21,7 +23,7 @@ from ddpg_trucktrailer_amd.replay_buffer import TrajectoryRing
 
 class DDPGRollout:
     def __init__(self, env, batch_size=256, replay_slots=64, seed=27, alpha=1e-4, beta=1e-3, tau=1e-3, gamma=0.99,
-                 fc1_dims=400, fc2_dims=300, world_size=1, use_graph=True, agent=None, fused_learn=True):
+                 fc1_dims=400, fc2_dims=300, world_size=1, use_graph=True, agent=None, fused_learn=True, graph_steps=4):
         self.env, self.n, self.device = env, env.n_envs, env.device
         self.batch_size = batch_size
         torch.manual_seed(seed)
@@ -55,11 +57,19 @@ class DDPGRollout:
         self.use_graph = use_graph and world_size == 1 and self.device.type == "cuda"
         self.graph = None
         self.vector_steps = 0
+        # whole-step graphs: the ring slots a step touches depend on k mod slots only, so a graph of G steps captured at
+        # ring position c*G is valid whenever k = c*G (mod slots): slots/G graphs cover the cycle
+        self.graph_steps = int(graph_steps) if (self.use_graph and self.learner is not None and graph_steps
+                                                and replay_slots % int(graph_steps) == 0) else 0
+        self.step_graphs = None
 
     # -------------------------------------------------------------- acting
     @torch.no_grad()
     def act(self, obs, act_out, done_prev=None):
         if self.fused_act:     # actor forward + OU noise + clip*high in ONE launch (tt_actor_act)
+            if self.ring._env_counts:      # noise keyed by the DEVICE step counter: the launch is graph-replayable
+                return fused.actor_act(self.agent.actor, obs, self.noise.x, act_out, self.scaled, seed=self.seed,
+                                       step=0, step_dev=self.ring.k_dev, done_prev=done_prev, high=self.high)
             return fused.actor_act(self.agent.actor, obs, self.noise.x, act_out, self.scaled, seed=self.seed,
                                    step=self.vector_steps, done_prev=done_prev, high=self.high)
         if done_prev is not None:
@@ -102,13 +112,48 @@ class DDPGRollout:
         self.graph.replay()
 
     # -------------------------------------------------------------- one vector step
-    def step(self):
+    def _act_and_step(self, k):
+        """The policy + env launches of vector step number k (k selects the ring slots; everything else is on the device)."""
         ring = self.ring
-        t, t1 = ring.slot(), ring.slot(ring.k + 1)
+        t, t1 = ring.slot(k), ring.slot(k + 1)
         # the noise of an env whose episode ended at the previous step restarts at 0 (trainv2.py:492)
-        done_prev = ring.done[ring.slot(ring.k - 1)] if ring.k > 0 else None
+        done_prev = ring.done[ring.slot(k - 1)] if k > 0 else None
         scaled = self.act(ring.obs[t], ring.act[t], done_prev)
         self.env.step(scaled, auto_reset=True, obs_out=ring.obs[t1], reward_out=ring.rew[t], done_out=ring.done[t])
-        ring.advance()
+
+    def step(self):
+        self._act_and_step(self.ring.k)
+        self.ring.advance()
         self.learn()
         self.vector_steps += 1
+
+    # -------------------------------------------------------------- many vector steps
+    def _capture_step_graphs(self):
+        ring, G = self.ring, self.graph_steps
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        self.step_graphs = []
+        for c in range(ring.slots // G):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                for i in range(G):
+                    self._act_and_step(ring.slots + c * G + i)      # + slots: any k > 0 with this ring position
+                    self._learn_once()
+            self.step_graphs.append(g)
+        torch.cuda.current_stream().wait_stream(side)
+
+    def run(self, k):
+        """k vector steps.  Whole-step hipGraphs whenever the ring position is a multiple of graph_steps and at least
+        graph_steps steps remain (after a few eager steps that warm everything up); eager step() otherwise."""
+        ring, G = self.ring, self.graph_steps
+        while k > 0:
+            if G and k >= G and ring.k >= 4 and ring.k % G == 0 and ring._env_counts:
+                if self.step_graphs is None:
+                    self._capture_step_graphs()
+                self.step_graphs[(ring.k % ring.slots) // G].replay()
+                ring.k += G                     # host mirror; the step kernels advanced k_dev
+                self.vector_steps += G
+                k -= G
+            else:
+                self.step()
+                k -= 1

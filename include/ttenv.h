@@ -244,6 +244,28 @@ typedef struct tt_mlp_saved {   /* what a forward keeps for its backward */
 int tt_mlp_forward_save(int n, int critic, const float *obs, const float *action, const tt_mlp_weights *w, float *out,
                         const tt_mlp_saved *saved, float *dq_da, tt_stream_t stream);
 
+/* Up to four tt_mlp_forward_save / tt_critic_state_forward jobs on n rows each in ONE launch (learn()'s first phase:
+ * target actor on s', target critic's state branch on s', Q(s,a), mu(s)).  critic = 0: actor (action, dq_da, z_state
+ * ignored); critic = 1 with z_state set: state branch only (action and out may be NULL); saved / dq_da may be NULL. */
+typedef struct tt_fwd_job {
+    int32_t critic, reserved_;
+    const float *obs, *action;
+    const tt_mlp_weights *w;
+    float *out;
+    const tt_mlp_saved *saved;
+    float *dq_da, *z_state;
+} tt_fwd_job;
+int tt_mlp_forward_multi(int n, int count, const tt_fwd_job *jobs, tt_stream_t stream);
+
+/* The target critic in two pieces, so that its state branch can run NEXT TO the target actor that produces its action:
+ * tt_critic_state_forward: z_state [n,300] = bn2(fc2(relu(bn1(fc1(s))))) (networks.py:55-61, before the action enters);
+ * tt_critic_head_td: q' = q(relu(z_state + action_value(a))) (networks.py:62-68) and the TD target
+ * y = r + gamma * q' * (1 - done) (DDPG_agent.py:89-93) in one launch; also advances *step_dev (may be NULL) like
+ * tt_td_target; q_out [n] may be NULL. */
+int tt_critic_state_forward(int n, const float *obs, const tt_mlp_weights *w, float *z_state, tt_stream_t stream);
+int tt_critic_head_td(int n, const float *z_state, const float *action, const tt_mlp_weights *w, const float *reward,
+                      const uint8_t *done, float gamma, float *y, float *q_out, int64_t *step_dev, tt_stream_t stream);
+
 /* Backward of one net on the batch (autograd of networks.py:55-68 / 138-147): workspace ws holds the per-row
  * gradients (dpre [B], dz, dx2 [B,300], dy1, dx1 [B,400]); grads has the layout of tt_mlp_weights and receives
  * d(loss)/d(parameter) for every parameter (overwritten, not accumulated).
@@ -257,6 +279,18 @@ typedef struct tt_mlp_bwd_ws {
 int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
                     const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
                     const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, tt_stream_t stream);
+
+/* tt_mlp_backward with the optimizer step of tt_adam_soft_update applied in the weight-gradient launch itself (each
+ * gradient element is finished by exactly one workgroup, which then updates that parameter, its Adam moments and its
+ * target): one launch less per network.  count = 10 (actor) / 12 (critic) tensors in tt_mlp_weights order; the arrays
+ * are HOST arrays of device pointers; grads still receives the gradients.  For the single-rank path: with data-parallel
+ * ranks the gradients are all-reduced between tt_mlp_backward and tt_adam_soft_update instead. */
+int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
+                         const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
+                         const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, int count,
+                         float *const *params, float *const *exp_avg, float *const *exp_avg_sq, float *const *targets,
+                         const int64_t *step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         float tau, tt_stream_t stream);
 
 /* optimizer.step() of torch.optim.Adam (weight decay folded into the gradient; networks.py:49-50,133) for `count`
  * (<= 12) parameter tensors in one launch, then the soft update of the matching target tensors

@@ -121,3 +121,56 @@ def test_fused_learn_in_hipgraph(gpu_device):
     for name in ("actor", "critic", "target_actor", "target_critic"):
         for x, y in zip(getattr(eager_agent, name).state_dict().values(), getattr(graph_agent, name).state_dict().values()):
             assert torch.equal(x, y), name
+
+
+def test_adam_inside_weight_gradient_launch_is_bit_identical(gpu_device):
+    """Single-rank learn() applies Adam + soft update inside k_bwd_weights (tt_mlp_backward_adam); ranks that all-reduce
+    their gradients run tt_mlp_backward, the collective, tt_adam_soft_update.  Same arithmetic: identical bits."""
+    import torch
+    from conftest import GOLDEN
+    from ddpg_trucktrailer_amd.fused_learn import FusedLearner
+    from test_learner import _batch
+    z = np.load(os.path.join(GOLDEN, "f5_learner.npz"), allow_pickle=False)
+    one, two = _agent(gpu_device, z), _agent(gpu_device, z)
+    s, a, r, s2, d = _batch(z, gpu_device)
+    d8 = d.to(torch.uint8)
+    f1, f2 = FusedLearner(one, 256), FusedLearner(two, 256)
+    f2.grad_sync_critic = f2.grad_sync_actor = lambda: None          # a no-op "all-reduce": forces the separate launches
+    for _ in range(3):
+        f1.learn_batch(s, a, r, s2, d8); f2.learn_batch(s, a, r, s2, d8)
+    torch.cuda.synchronize()
+    for name in ("actor", "critic", "target_actor", "target_critic"):
+        for x, y in zip(getattr(one, name).state_dict().values(), getattr(two, name).state_dict().values()):
+            assert torch.equal(x, y), name
+    assert torch.equal(f1.critic.m, f2.critic.m) and torch.equal(f1.actor.v, f2.actor.v)
+    assert torch.equal(f1.critic.flat_grad, f2.critic.flat_grad)     # the gradients are still written
+
+
+def test_target_critic_in_two_pieces(gpu_device):
+    """tt_critic_state_forward + tt_critic_head_td (the state branch next to the target actor, then q' and the TD target
+    in one small launch) against the one-piece critic forward + tt_td_target."""
+    import ctypes as C
+    import torch
+    from ddpg_trucktrailer_amd import _lib as L, fused
+    from ddpg_trucktrailer_amd.fused_learn import _p
+    B = 200
+    actor, critic, s, a, g = _setup(gpu_device, seed=9, B=B)
+    lib = L.load()
+    f = dict(dtype=torch.float32, device=gpu_device)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    r = torch.randn(B, generator=g, **f)
+    done = (torch.rand(B, device=gpu_device, generator=g) < 0.3).to(torch.uint8)
+    z, y, q, y_ref, q_ref = torch.empty((B, 300), **f), torch.empty(B, **f), torch.empty(B, **f), torch.empty(B, **f), torch.empty(B, **f)
+    w = fused.weights_of(critic)
+    L.check(lib.tt_critic_state_forward(B, _p(s), C.byref(w), _p(z), stream))
+    step = torch.zeros((), dtype=torch.int64, device=gpu_device)
+    L.check(lib.tt_critic_head_td(B, _p(z), _p(a), C.byref(w), _p(r), _p(done), 0.99, _p(y), _p(q), _p(step), stream))
+    L.check(lib.tt_mlp_forward_save(B, 1, _p(s), _p(a), C.byref(w), _p(q_ref), None, None, stream))
+    L.check(lib.tt_td_target(B, _p(r), _p(q_ref), _p(done), 0.99, _p(y_ref), None, stream))
+    with torch.no_grad():
+        z_ref = critic.bn2(critic.fc2(torch.relu(critic.bn1(critic.fc1(s)))))
+        q_t = critic(s, a).view(-1)
+    assert (z - z_ref).abs().max().item() <= 2e-5
+    assert (q - q_ref).abs().max().item() <= 1e-5 and (q - q_t).abs().max().item() <= 2e-5 * max(1.0, q_t.abs().max().item())
+    assert (y - y_ref).abs().max().item() <= 1e-5 and int(step.item()) == 1
+    assert torch.equal(y[done.bool()], r[done.bool()])               # critic_value_[done] = 0 (DDPG_agent.py:89)

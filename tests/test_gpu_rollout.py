@@ -155,3 +155,36 @@ def test_fused_ring_sampling(gpu_device):
     again = ring.sample_fused(B, seed=5, return_index=True)[5].clone()
     ring.advance()
     assert not torch.equal(again, ring.sample_fused(B, seed=5, return_index=True)[5])
+
+
+def test_whole_step_graphs_match_eager_steps(gpu_device):
+    """DDPGRollout.run(k) replays hipGraphs of whole vector steps (policy + env step + learn); step() launches the same
+    vector step eagerly.  Everything that varies per step lives on the device (ring counter, Philox counters), so the two
+    must agree bit for bit: ring contents, env state, noise state, all four networks."""
+    import torch
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    n, k = 2048, 26
+    loops = []
+    for graph_steps in (4, 0):
+        env = TruckTrailerVecEnv(n)
+        env.reset(seed=5)
+        loop = DDPGRollout(env, batch_size=256, replay_slots=8, seed=5, use_graph=True, graph_steps=graph_steps)
+        loops.append(loop)
+    a, b = loops
+    assert a.graph_steps == 4 and b.graph_steps == 0
+    a.run(k)                       # 4 eager steps, 5 graphs of 4, 2 eager steps
+    for _ in range(k):
+        b.step()
+    torch.cuda.synchronize()
+    assert a.step_graphs is not None and len(a.step_graphs) == 2
+    assert a.ring.k == b.ring.k == k and int(a.ring.k_dev.item()) == int(b.ring.k_dev.item()) == k
+    for name in ("obs", "act", "rew", "done"):
+        assert torch.equal(getattr(a.ring, name), getattr(b.ring, name)), name
+    assert torch.equal(a.noise.x, b.noise.x) and torch.equal(a.env.state, b.env.state)
+    for net in ("actor", "critic", "target_actor", "target_critic"):
+        for x, y in zip(getattr(a.agent, net).state_dict().values(), getattr(b.agent, net).state_dict().values()):
+            assert torch.equal(x, y), net
+    assert int(a.learner.step_dev.item()) == int(b.learner.step_dev.item()) >= k - 1    # learn() from the 2nd step on
+    for lp in loops:
+        lp.env.close()
