@@ -105,8 +105,25 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
 
     STAMP(0);
+    constexpr int MT1 = (NT1 + NW - 1) / NW, MT2 = (NT2 + NW - 1) / NW;
+    // every per-column vector this lane will need, loaded NOW: the uses sit behind barriers (the cross-wave LayerNorm
+    // reductions), which the compiler cannot move a load across, so each would cost an exposed L2 round trip there
+    float pb1[MT1], pg1[MT1], pbe1[MT1], pb2[MT2], pg2[MT2], pbe2[MT2], pw3[MT2], pwa[MT2], pba[MT2];
+#pragma unroll
+    for (int i = 0; i < MT1; ++i) {
+        const int t = wave + NW * i, col = t * 16 + l15;
+        const bool real = t < NT1;
+        pb1[i] = real ? W.b1[col] : 0.f; pg1[i] = real ? W.g1[col] : 0.f; pbe1[i] = real ? W.be1[col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < MT2; ++i) {
+        const int col = (wave + NW * i) * 16 + l15;
+        const bool real = wave + NW * i < NT2 && col < H2;
+        pb2[i] = real ? W.b2[col] : 0.f; pg2[i] = real ? W.g2[col] : 0.f; pbe2[i] = real ? W.be2[col] : 0.f;
+        pw3[i] = real ? W.w3[col] : 0.f;
+        pwa[i] = (CRITIC && real) ? W.wa[col] : 0.f; pba[i] = (CRITIC && real) ? W.ba[col] : 0.f;
+    }
     // ---- layer 1 (K = 23): operands straight from global; this wave's column tiles t = wave, wave+NW, ...
-    constexpr int MT1 = (NT1 + NW - 1) / NW;
     f32x4 acc1[MT1];
 #pragma unroll
     for (int i = 0; i < MT1; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -138,7 +155,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
     for (int i = 0; i < MT1; ++i) {
         const int t = wave + NW * i;
         if (t < NT1) {
-            const float bias = W.b1[t * 16 + l15];
+            const float bias = pb1[i];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc1[i][r] += bias; s[r] += acc1[i][r]; }
         }
@@ -171,7 +188,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
         const int t = wave + NW * i;
         if (t < NT1) {
             const int col = t * 16 + l15;
-            const float g = W.g1[col], be = W.be1[col];
+            const float g = pg1[i], be = pbe1[i];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int lr = l4 * 4 + r;
@@ -191,7 +208,6 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
     // ---- layer 2: this wave's column tiles t = wave, wave+NW, ... (3 or 2 of the 20); A from the LDS tile (one
     // ds_read_b128 per k16 step), B = fc2 rows straight from L2 (one float4 per tile per k16 step), k visited in
     // the permuted order described above
-    constexpr int MT2 = (NT2 + NW - 1) / NW;
     f32x4 acc2[MT2];
 #pragma unroll
     for (int i = 0; i < MT2; ++i) acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -232,7 +248,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
     for (int i = 0; i < MT2; ++i) {
         const int col = (wave + NW * i) * 16 + l15;
         const bool real = wave + NW * i < NT2 && col < H2;
-        const float bias = real ? W.b2[col] : 0.f;
+        const float bias = pb2[i];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { acc2[i][r] = real ? acc2[i][r] + bias : 0.f; s[r] += acc2[i][r]; }
     }
@@ -265,7 +281,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
         for (int i = 0; i < MT2; ++i) {
             const int col = (wave + NW * i) * 16 + l15;
             if (wave + NW * i < NT2 && col < H2) {
-                const float g = W.g2[col], be = W.be2[col];
+                const float g = pg2[i], be = pbe2[i];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = row0 + l4 * 4 + r;
@@ -287,9 +303,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
     for (int i = 0; i < MT2; ++i) {
         const int col = (wave + NW * i) * 16 + l15;
         if (wave + NW * i < NT2 && col < H2) {
-            const float g = W.g2[col], be = W.be2[col], w3 = W.w3[col];
-            float wa = 0.f, ba = 0.f;
-            if (CRITIC) { wa = W.wa[col]; ba = W.ba[col]; }
+            const float g = pg2[i], be = pbe2[i], w3 = pw3[i], wa = pwa[i], ba = pba[i];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int lr = l4 * 4 + r;
@@ -534,7 +548,6 @@ struct AdamFused {
     float lr, beta1, beta2, eps, weight_decay, tau;
     int on;
 };
-struct AdamCoef { float step_size, rsqrt_bc2; };      // lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t) as k_adam_soft forms them
 
 __device__ __forceinline__ void adam_apply(const AdamFused &A, const int t, const size_t i, const float grad,
                                            const float bc1, const float sqrt_bc2) {

@@ -38,7 +38,11 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int ROWS = 128, WROWS = 32;       // envs per workgroup / per wave
 constexpr int T1 = 13, H1P = 32 * T1;       // layer-1 neuron tiles (416 >= 400)
 constexpr int T2 = 10, H2P = 32 * T2;       // layer-2 neuron tiles (320 >= 300)
+#ifdef TT_DBG_STEPS                         // timing experiments only (wrong results): fewer k16 steps of layer 2
+constexpr int STEPS = TT_DBG_STEPS;
+#else
 constexpr int STEPS = H1 / 16;              // 25 k16 steps of layer 2
+#endif
 constexpr int KQ = 12;                      // k2 steps of layer 1 (24 >= 23)
 constexpr int PIECES = 32;                  // one k16 step of packed fc2 = 10 tiles x 3 planes = 30 pieces of 64 lanes x 16 B,
                                             // padded to 32 so that each of the 4 waves moves exactly 8 pieces

@@ -113,25 +113,31 @@ class FusedLearner:
                                              lr, b1, b2, eps, wd, tau, self._stream()))
 
     def enable_data_parallel(self, group=None):
-        """All-reduce (mean) of the flat gradient buffers at the reference's two optimizer sites."""
+        """Mean of the flat gradient buffers over the ranks at the reference's two optimizer sites (RCCL: one AVG
+        all-reduce per site, straight on the flat buffer; other backends: SUM, then a divide)."""
         import torch.distributed as dist
         world = dist.get_world_size(group)
+        avg = dist.get_backend(group) == "nccl"
 
         def sync(flat):
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-            flat.div_(world)
+            if avg:
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+                flat.div_(world)
         self.grad_sync_critic = lambda: sync(self.critic.flat_grad)
         self.grad_sync_actor = lambda: sync(self.actor.flat_grad)
 
-    def learn_batch(self, states, actions, rewards, states_, done_u8):
-        """states, states_ [B,23] f32; actions [B,1] f32; rewards [B] f32; done_u8 [B] uint8 -- all contiguous."""
+    # learn() in the three pieces the two gradient all-reduces cut it into (each piece is pure kernel launches on the
+    # current stream, so a data-parallel loop can capture each as a hipGraph and keep only the collectives eager)
+    def phase_a(self, states, actions, rewards, states_, done_u8, fuse_adam):
+        """Forwards, TD target, critic backward (+ the critic's Adam/soft update in the same launch when fuse_adam)."""
         ag, B = self.agent, self.B
-        assert states.shape[0] == B and done_u8.dtype == torch.uint8
         # DDPG_agent.py:85-93 and :87, :101.  Only the target critic's LAST step needs the target actor's action (it enters
         # after LayerNorm2, networks.py:62-66), so four passes run side by side -- target actor on s', the target critic's
         # state branch on s', Q(s,a), mu(s), each filling 16 of the 256 CUs -- and one small launch then finishes
         # q'(s', mu'(s')) and the TD target.  The four are ONE launch (tt_mlp_forward_multi): a stream fork/join inside
-        # the captured graph costs more than the kernel it would hide
+        # a captured graph costs more than the kernel it would hide
         def ptr(t):
             return None if t is None else t.data_ptr()
         jobs = (L.TTFwdJob * 4)()
@@ -149,20 +155,37 @@ class FusedLearner:
                                            _p(rewards), _p(done_u8), float(ag.gamma), _p(self.y), _p(self.q_t),
                                            _p(self.step_dev), self._stream()))
         # critic step (DDPG_agent.py:95-98)
-        if self.grad_sync_critic is None:
+        if fuse_adam:
             self._bwd_adam(self.critic, self.hyp_critic, ag.tau, 1, 2.0 / B, states, actions, self.q, y=self.y)
         else:
             self._bwd(self.critic, 1, 2.0 / B, states, actions, self.q, y=self.y)
-            self.grad_sync_critic()
+
+    def phase_b(self, states, separate_adam):
+        """[critic Adam/soft update when not already applied,] then the actor step through the UPDATED critic
+        (DDPG_agent.py:100-104): Q(s, mu(s)) with dQ/da, actor backward (+ its Adam unless separate_adam)."""
+        ag, B = self.agent, self.B
+        if separate_adam:
             self._adam(self.critic, self.hyp_critic, ag.tau)
-        # actor step through the UPDATED critic (DDPG_agent.py:100-104)
         self._fwd(ag.critic, states, self.mu, self.q_pi, None, self.dq_da)
-        if self.grad_sync_actor is None:
-            self._bwd_adam(self.actor, self.hyp_actor, ag.tau, 2, -1.0 / B, states, None, self.mu, aux=self.dq_da)
-        else:
+        if separate_adam:
             self._bwd(self.actor, 2, -1.0 / B, states, None, self.mu, aux=self.dq_da)
+        else:
+            self._bwd_adam(self.actor, self.hyp_actor, ag.tau, 2, -1.0 / B, states, None, self.mu, aux=self.dq_da)
+
+    def phase_c(self):
+        self._adam(self.actor, self.hyp_actor, self.agent.tau)
+
+    def learn_batch(self, states, actions, rewards, states_, done_u8):
+        """states, states_ [B,23] f32; actions [B,1] f32; rewards [B] f32; done_u8 [B] uint8 -- all contiguous."""
+        assert states.shape[0] == self.B and done_u8.dtype == torch.uint8
+        dp = self.grad_sync_critic is not None
+        self.phase_a(states, actions, rewards, states_, done_u8, fuse_adam=not dp)
+        if dp:
+            self.grad_sync_critic()
+        self.phase_b(states, separate_adam=dp)
+        if dp:
             self.grad_sync_actor()
-            self._adam(self.actor, self.hyp_actor, ag.tau)
+            self.phase_c()
 
     # ---- checkpoint interoperability with the torch optimizers ------------------------------------------
     def export_to_optimizers(self):

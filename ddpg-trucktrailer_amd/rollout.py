@@ -54,13 +54,16 @@ class DDPGRollout:
             self.agent.fused_learner = self.learner
             if world_size > 1:
                 self.learner.enable_data_parallel()
-        self.use_graph = use_graph and world_size == 1 and self.device.type == "cuda"
+        self.use_graph = use_graph and self.device.type == "cuda"
+        self.dp = world_size > 1
         self.graph = None
         self.vector_steps = 0
         # whole-step graphs: the ring slots a step touches depend on k mod slots only, so a graph of G steps captured at
         # ring position c*G is valid whenever k = c*G (mod slots): slots/G graphs cover the cycle
         self.graph_steps = int(graph_steps) if (self.use_graph and self.learner is not None and graph_steps
                                                 and replay_slots % int(graph_steps) == 0) else 0
+        if self.dp and self.graph_steps:
+            self.graph_steps = 1        # data-parallel: a step is three graphs with the two gradient all-reduces between
         self.step_graphs = None
 
     # -------------------------------------------------------------- acting
@@ -93,7 +96,7 @@ class DDPGRollout:
     def learn(self):
         if self.ring.k < 2:
             return
-        if not self.use_graph:
+        if not self.use_graph or self.dp:      # (collectives are not captured)
             return self._learn_once()
         if self.graph is None:
             # warm up (allocator, Adam state, autograd's AccumulateGrad nodes) on the SAME side stream the
@@ -138,9 +141,30 @@ class DDPGRollout:
             with torch.cuda.graph(g, stream=side):
                 for i in range(G):
                     self._act_and_step(ring.slots + c * G + i)      # + slots: any k > 0 with this ring position
-                    self._learn_once()
+                    if self.dp:                                     # up to the critic's gradient; see _dp_step
+                        s, a, r, s2, d = ring.sample_fused(self.batch_size, seed=self.seed, done_as_bool=False)
+                        self.learner.phase_a(s, a, r, s2, d, fuse_adam=False)
+                    else:
+                        self._learn_once()
             self.step_graphs.append(g)
+        if self.dp:
+            s = ring._bufs[0]
+            self.dp_graphs = []
+            for fn in (lambda: self.learner.phase_b(s, separate_adam=True), self.learner.phase_c):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    fn()
+                self.dp_graphs.append(g)
         torch.cuda.current_stream().wait_stream(side)
+
+    def _dp_step(self):
+        """One data-parallel vector step: three graph replays with the reference's two optimizer-site all-reduces
+        (DDPG_agent.py:95-104) between them, launched eagerly on the flat gradient buffers."""
+        self.step_graphs[self.ring.k % self.ring.slots].replay()
+        self.learner.grad_sync_critic()
+        self.dp_graphs[0].replay()
+        self.learner.grad_sync_actor()
+        self.dp_graphs[1].replay()
 
     def run(self, k):
         """k vector steps.  Whole-step hipGraphs whenever the ring position is a multiple of graph_steps and at least
@@ -150,7 +174,10 @@ class DDPGRollout:
             if G and k >= G and ring.k >= 4 and ring.k % G == 0 and ring._env_counts:
                 if self.step_graphs is None:
                     self._capture_step_graphs()
-                self.step_graphs[(ring.k % ring.slots) // G].replay()
+                if self.dp:
+                    self._dp_step()
+                else:
+                    self.step_graphs[(ring.k % ring.slots) // G].replay()
                 ring.k += G                     # host mirror; the step kernels advanced k_dev
                 self.vector_steps += G
                 k -= G
