@@ -243,6 +243,29 @@ def main():
                      "kernel_ms": kern_ms, "alg_bytes_per_env_step": B_ALG,
                      "kernel_env_steps_per_s": n / (kern_ms * 1e-3)},
     }
+    if ddpg_loop is not None and ddpg_loop.fused_act:
+        # the loop's largest kernel is the N-env policy forward (k_split_pack + k_mlp_split, csrc/ttnet_split.hip): MFMA-bound.
+        # Events on the launch stream around 20 back-to-back choose_action launches, right after the timed region.
+        ring = ddpg_loop.ring
+        t = ring.slot()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ddpg_loop.act(ring.obs[t], ring.act[t], None)
+        e0.record()
+        for _ in range(20):
+            ddpg_loop.act(ring.obs[t], ring.act[t], None)
+        e1.record()
+        torch.cuda.synchronize()
+        act_ms = e0.elapsed_time(e1) / 20
+        waves = 4 * ((n + 127) // 128)
+        bf16_flop = waves * 1500 * 32768.0          # v_mfma_f32_32x32x16_bf16: 25 k16 steps x 10 tiles x 6 products per wave
+        out["roofline_mfma"] = {
+            "bound": "mfma", "kernel": "k_split_pack + k_mlp_split (choose_action for N envs)", "kernel_ms": act_ms,
+            "achieved": bf16_flop / (act_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": bf16_flop / (act_ms * 1e-3) / 1e12 / 2500.0, "traffic": None,
+            "note": "bf16 MFMA FLOP executed (six bf16 products per f32 product block) over dense bf16 peak; layer 1 "
+                    "(f32 MFMA, 2 % of the FLOP) not counted",
+            "algorithmic_f32_tflops": 2.0 * n * (23 * 400 + 400 * 300 + 300) / (act_ms * 1e-3) / 1e12,
+            "f32_mfma_peak_tflops": 157.3}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
