@@ -184,6 +184,8 @@ def main():
                            world_size=world, use_graph=not args.no_graph, fused_learn=not args.torch_learn,
                            graph_steps=args.step_graph)
 
+        loop.prepare()       # one-off work (4 untimed vector steps + graph capture) before warm-up and the timed region
+
         def one_step(timed):
             loop.step()
         ddpg_loop = loop

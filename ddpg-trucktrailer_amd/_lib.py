@@ -47,6 +47,12 @@ class TTFwdJob(C.Structure):
                 ("dq_da", C.c_void_p), ("z_state", C.c_void_p)]
 
 
+class TTTdInput(C.Structure):
+    _fields_ = [("z_state", C.c_void_p), ("mu_target", C.c_void_p), ("target_critic", C.POINTER(TTMlpWeights)),
+                ("reward", C.c_void_p), ("done", C.c_void_p), ("gamma", C.c_float), ("reserved_", C.c_float),
+                ("y_out", C.c_void_p), ("q_out", C.c_void_p), ("step_dev", C.c_void_p)]
+
+
 class TTMlpBwdWs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dpre", "dz", "dx2", "dy1", "dx1")]
 
@@ -92,10 +98,12 @@ _SIGNATURES = {
     "tt_critic_state_forward": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_critic_head_td": (C.c_int, [_I, _P, _P, C.POINTER(TTMlpWeights), _P, _P, C.c_float, _P, _P, _P, _P]),
     "tt_mlp_backward": (C.c_int, [_I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, C.POINTER(TTMlpWeights),
-                                  C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights), _P]),
+                                  C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights), C.POINTER(TTTdInput),
+                                  _P]),
     "tt_mlp_backward_adam": (C.c_int, [_I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, C.POINTER(TTMlpWeights),
                                        C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights), _I, _P, _P, _P,
-                                       _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+                                       _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.POINTER(TTTdInput), _P]),
     "tt_adam_soft_update": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                       C.c_float, C.c_float, _P]),
     "tt_td_target": (C.c_int, [_I, _P, _P, _P, C.c_float, _P, _P, _P]),

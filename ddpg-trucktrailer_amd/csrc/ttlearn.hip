@@ -403,11 +403,23 @@ __device__ __forceinline__ float wave_sum64(float v) {
     return v;
 }
 
+// Optional prologue of the critic's backward: the rest of the TARGET critic once the target actor's action is known
+// (networks.py:62-68) and the TD target (DDPG_agent.py:89-93), for the rows this workgroup owns -- what k_head_td does
+// as a launch of its own.  q'[b] = q(relu(z_state[b] + action_value(mu'[b]))), y[b] = r[b] + gamma q'[b] (1 - done[b]).
+struct TdIn {
+    const float *__restrict__ z_state, *__restrict__ mu_t, *__restrict__ r;
+    const uint8_t *__restrict__ done;
+    const float *__restrict__ wa, *__restrict__ ba, *__restrict__ w3, *__restrict__ b3;     // the target critic's
+    float gamma;
+    float *__restrict__ y_out, *__restrict__ q_out;
+    long long *__restrict__ step_dev;
+};
+
 template <bool CRITIC>
 __global__ __launch_bounds__(64 * NW) void k_bwd_rows(const int n, const int mode, const float scale,
                                                       const float *__restrict__ d_out, const float *__restrict__ out,
                                                       const float *__restrict__ y, const float *__restrict__ aux,
-                                                      const Weights W, const Saved sv, const BwdOut o) {
+                                                      const Weights W, const Saved sv, const BwdOut o, const TdIn td) {
     __shared__ __attribute__((aligned(16))) float dx2_s[TR * DS];    // [16][308]
     __shared__ float red[NW * TR];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
@@ -418,8 +430,32 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows(const int n, const int mod
     for (int rr = 0; rr < TR / NW; ++rr) {
         const int lr = wave * (TR / NW) + rr, row = row0 + lr;
         float dpre = 0.f;
+        float y_td = 0.f;
+        if (CRITIC && td.z_state) {                          // (uniform over the workgroup)
+            float dot = 0.f;
+            if (row < n) {
+                const float a = td.mu_t[row];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int c = lane + 64 * i;
+                    if (c < H2)
+                        dot = fmaf(fmaxf(td.z_state[(size_t)row * H2 + c] + fmaf(a, td.wa[c], td.ba[c]), 0.f), td.w3[c], dot);
+                }
+            }
+            dot = wave_sum64(dot);
+            if (row < n) {
+                const float q = dot + td.b3[0];
+                y_td = td.done[row] ? td.r[row] : fmaf(td.gamma, q, td.r[row]);
+                if (lane == 0) {
+                    td.y_out[row] = y_td;
+                    if (td.q_out) td.q_out[row] = q;
+                }
+            }
+            if (blockIdx.x == 0 && tid == 0 && rr == 0 && td.step_dev) *td.step_dev += 1;
+        }
         if (row < n) {
-            float g = mode == 0 ? d_out[row] : (mode == 1 ? scale * (out[row] - y[row]) : scale * aux[row]);
+            float g = mode == 0 ? d_out[row]
+                                : (mode == 1 ? scale * (out[row] - ((CRITIC && td.z_state) ? y_td : y[row])) : scale * aux[row]);
             if (!CRITIC) { const float mu = out[row]; g *= (1.f - mu * mu); }
             dpre = g;
         }
@@ -910,10 +946,19 @@ int tt_critic_head_td(int n, const float *z_state, const float *action, const tt
 static int backward_impl(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
                          const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
                          const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const AdamFused &A,
-                         tt_stream_t stream) {
+                         const tt_td_input *tdi, tt_stream_t stream) {
     if (n <= 0 || !obs || !out || !ok_shape(w, critic != 0) || !ok_shape(grads, critic != 0) || !saved || !ws ||
-        (critic && !action) || mode < 0 || mode > 2 || (mode == 0 && !d_out) || (mode == 1 && !y) || (mode == 2 && !aux))
+        (critic && !action) || mode < 0 || mode > 2 || (mode == 0 && !d_out) || (mode == 1 && !y && !tdi) || (mode == 2 && !aux))
         return TT_EINVAL;
+    TdIn td{};
+    if (tdi) {
+        const tt_mlp_weights *tw = tdi->target_critic;
+        if (!critic || mode != 1 || !tdi->z_state || !tdi->mu_target || !ok_shape(tw, true) || !tdi->reward || !tdi->done ||
+            !tdi->y_out)
+            return TT_EINVAL;
+        td = TdIn{tdi->z_state, tdi->mu_target, tdi->reward, tdi->done, tw->wa, tw->ba, tw->w3, tw->b3, tdi->gamma,
+                  tdi->y_out, tdi->q_out, reinterpret_cast<long long *>(tdi->step_dev)};
+    }
     if (!saved->xh1 || !saved->h1 || !saved->xh2 || !saved->h2 || !saved->rstd1 || !saved->rstd2 || !ws->dpre || !ws->dz ||
         !ws->dx2 || !ws->dy1 || !ws->dx1)
         return TT_EINVAL;
@@ -922,10 +967,10 @@ static int backward_impl(int n, int critic, int mode, float scale, const float *
     const dim3 grid((n + TR - 1) / TR), block(256), block_rows(64 * NW);
     if (critic)
         hipLaunchKernelGGL(k_bwd_rows<true>, grid, block_rows, 0, stream, n, mode, scale, d_out, out, y, aux,
-                           to_weights(w), sv, o);
+                           to_weights(w), sv, o, td);
     else
         hipLaunchKernelGGL(k_bwd_rows<false>, grid, block_rows, 0, stream, n, mode, scale, d_out, out, y, aux,
-                           to_weights(w), sv, o);
+                           to_weights(w), sv, o, td);
     if (hipGetLastError() != hipSuccess) return TT_EHIP;
     const Grads G{const_cast<float *>(grads->w1), const_cast<float *>(grads->b1), const_cast<float *>(grads->g1),
                   const_cast<float *>(grads->be1), const_cast<float *>(grads->w2), const_cast<float *>(grads->b2),
@@ -938,9 +983,10 @@ static int backward_impl(int n, int critic, int mode, float scale, const float *
 
 int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
                     const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
-                    const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, tt_stream_t stream) {
+                    const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const tt_td_input *td,
+                    tt_stream_t stream) {
     AdamFused A{};
-    return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, stream);
+    return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, td, stream);
 }
 
 int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
@@ -948,7 +994,7 @@ int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *
                          const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, int count,
                          float *const *params, float *const *exp_avg, float *const *exp_avg_sq, float *const *targets,
                          const int64_t *step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
-                         float tau, tt_stream_t stream) {
+                         float tau, const tt_td_input *td, tt_stream_t stream) {
     if (count != (critic ? 12 : 10) || !params || !exp_avg || !exp_avg_sq || !step_dev) return TT_EINVAL;
     AdamFused A{};
     for (int i = 0; i < count; ++i) {
@@ -958,7 +1004,7 @@ int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *
     A.step_dev = reinterpret_cast<const long long *>(step_dev);
     A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.weight_decay = weight_decay; A.tau = tau;
     A.on = 1;
-    return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, stream);
+    return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, td, stream);
 }
 
 int tt_adam_soft_update(int count, float *const *params, const float *const *grads, float *const *exp_avg,

@@ -93,19 +93,20 @@ class FusedLearner:
                                              C.byref(fused.weights_of(net)), _p(out), C.byref(saved) if saved else None,
                                              _p(dq_da), self._stream()))
 
-    def _bwd(self, st, mode, scale, obs, action, out, y=None, aux=None):
+    def _bwd(self, st, mode, scale, obs, action, out, y=None, aux=None, td=None):
         L.check(self.lib.tt_mlp_backward(self.B, 1 if st.critic else 0, mode, float(scale), _p(obs), _p(action), None,
                                          _p(out), _p(y), _p(aux), C.byref(fused.weights_of(st.net)), C.byref(st.saved),
-                                         C.byref(self.ws), C.byref(st.gstruct), self._stream()))
+                                         C.byref(self.ws), C.byref(st.gstruct), C.byref(td) if td is not None else None,
+                                         self._stream()))
 
-    def _bwd_adam(self, st, hyp, tau, mode, scale, obs, action, out, y=None, aux=None):
+    def _bwd_adam(self, st, hyp, tau, mode, scale, obs, action, out, y=None, aux=None, td=None):
         """_bwd + _adam in the backward's own two launches (include/ttenv.h: tt_mlp_backward_adam)."""
         lr, b1, b2, eps, wd = hyp
         L.check(self.lib.tt_mlp_backward_adam(self.B, 1 if st.critic else 0, mode, float(scale), _p(obs), _p(action), None,
                                               _p(out), _p(y), _p(aux), C.byref(fused.weights_of(st.net)),
                                               C.byref(st.saved), C.byref(self.ws), C.byref(st.gstruct), st.count, st.a_p,
                                               st.a_m, st.a_v, st.a_t, _p(self.step_dev), lr, b1, b2, eps, wd, tau,
-                                              self._stream()))
+                                              C.byref(td) if td is not None else None, self._stream()))
 
     def _adam(self, st, hyp, tau):
         lr, b1, b2, eps, wd = hyp
@@ -135,7 +136,7 @@ class FusedLearner:
         ag, B = self.agent, self.B
         # DDPG_agent.py:85-93 and :87, :101.  Only the target critic's LAST step needs the target actor's action (it enters
         # after LayerNorm2, networks.py:62-66), so four passes run side by side -- target actor on s', the target critic's
-        # state branch on s', Q(s,a), mu(s), each filling 16 of the 256 CUs -- and one small launch then finishes
+        # state branch on s', Q(s,a), mu(s), each filling 16 of the 256 CUs -- and the critic's backward then finishes
         # q'(s', mu'(s')) and the TD target.  The four are ONE launch (tt_mlp_forward_multi): a stream fork/join inside
         # a captured graph costs more than the kernel it would hide
         def ptr(t):
@@ -151,14 +152,16 @@ class FusedLearner:
             jobs[j].saved = C.pointer(saved) if saved is not None else None
             jobs[j].dq_da, jobs[j].z_state = None, ptr(zst)
         L.check(self.lib.tt_mlp_forward_multi(B, 4, jobs, self._stream()))
-        L.check(self.lib.tt_critic_head_td(B, _p(self.z_t), _p(self.mu_t), C.byref(fused.weights_of(ag.target_critic)),
-                                           _p(rewards), _p(done_u8), float(ag.gamma), _p(self.y), _p(self.q_t),
-                                           _p(self.step_dev), self._stream()))
-        # critic step (DDPG_agent.py:95-98)
+        # critic step (DDPG_agent.py:95-98); its backward launch first finishes q'(s', mu'(s')) and the TD target for its
+        # rows (tt_td_input: what tt_critic_head_td does as a launch of its own)
+        td = L.TTTdInput(z_state=self.z_t.data_ptr(), mu_target=self.mu_t.data_ptr(),
+                         target_critic=C.pointer(fused.weights_of(ag.target_critic)), reward=rewards.data_ptr(),
+                         done=done_u8.data_ptr(), gamma=float(ag.gamma), y_out=self.y.data_ptr(),
+                         q_out=self.q_t.data_ptr(), step_dev=self.step_dev.data_ptr())
         if fuse_adam:
-            self._bwd_adam(self.critic, self.hyp_critic, ag.tau, 1, 2.0 / B, states, actions, self.q, y=self.y)
+            self._bwd_adam(self.critic, self.hyp_critic, ag.tau, 1, 2.0 / B, states, actions, self.q, td=td)
         else:
-            self._bwd(self.critic, 1, 2.0 / B, states, actions, self.q, y=self.y)
+            self._bwd(self.critic, 1, 2.0 / B, states, actions, self.q, td=td)
 
     def phase_b(self, states, separate_adam):
         """[critic Adam/soft update when not already applied,] then the actor step through the UPDATED critic

@@ -166,6 +166,20 @@ class DDPGRollout:
         self.learner.grad_sync_actor()
         self.dp_graphs[1].replay()
 
+    def prepare(self):
+        """Everything one-off that run() would otherwise do lazily inside the first calls (a few eager vector steps that
+        warm up allocators / kernel attributes / Adam state, then the graph captures), so that a timed region holds
+        steady-state steps only.  Advances the loop by 4 vector steps."""
+        while self.ring.k < 4 or (self.graph_steps and self.ring.k % self.graph_steps):
+            self.step()
+        if self.graph_steps and self.step_graphs is None and self.ring._env_counts:
+            try:
+                self._capture_step_graphs()
+            except Exception as exc:
+                import warnings
+                warnings.warn(f"whole-step hipGraph capture failed ({exc!r}); continuing with eager steps")
+                self.step_graphs, self.graph_steps = None, 0
+
     def run(self, k):
         """k vector steps.  Whole-step hipGraphs whenever the ring position is a multiple of graph_steps and at least
         graph_steps steps remain (after a few eager steps that warm everything up); eager step() otherwise."""
@@ -173,7 +187,14 @@ class DDPGRollout:
         while k > 0:
             if G and k >= G and ring.k >= 4 and ring.k % G == 0 and ring._env_counts:
                 if self.step_graphs is None:
-                    self._capture_step_graphs()
+                    try:
+                        self._capture_step_graphs()
+                    except Exception as exc:        # capture refused (driver / library state): the eager path is the same bits
+                        import warnings
+                        warnings.warn(f"whole-step hipGraph capture failed ({exc!r}); continuing with eager steps")
+                        self.step_graphs, self.graph_steps = None, 0
+                        G = 0
+                        continue
                 if self.dp:
                     self._dp_step()
                 else:

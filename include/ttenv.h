@@ -276,9 +276,23 @@ int tt_critic_head_td(int n, const float *z_state, const float *action, const tt
 typedef struct tt_mlp_bwd_ws {
     float *dpre, *dz, *dx2, *dy1, *dx1;
 } tt_mlp_bwd_ws;
+/* td (optional, critic with mode 1 only; y may then be NULL): the work of tt_critic_head_td done as the prologue of the
+ * critic's backward launch instead of a launch of its own -- q' from the target critic's state branch z_state [n,300] and
+ * the target actor's action mu_target [n], y_out [n] = r + gamma q' (1 - done) (used as y and written out), q_out [n] or
+ * NULL, *step_dev advanced by 1 (may be NULL). */
+typedef struct tt_td_input {
+    const float *z_state, *mu_target;
+    const tt_mlp_weights *target_critic;
+    const float *reward;
+    const uint8_t *done;
+    float gamma, reserved_;
+    float *y_out, *q_out;
+    int64_t *step_dev;
+} tt_td_input;
 int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
                     const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
-                    const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, tt_stream_t stream);
+                    const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const tt_td_input *td,
+                    tt_stream_t stream);
 
 /* tt_mlp_backward with the optimizer step of tt_adam_soft_update applied in the weight-gradient launch itself (each
  * gradient element is finished by exactly one workgroup, which then updates that parameter, its Adam moments and its
@@ -290,7 +304,7 @@ int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *
                          const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, int count,
                          float *const *params, float *const *exp_avg, float *const *exp_avg_sq, float *const *targets,
                          const int64_t *step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
-                         float tau, tt_stream_t stream);
+                         float tau, const tt_td_input *td, tt_stream_t stream);
 
 /* optimizer.step() of torch.optim.Adam (weight decay folded into the gradient; networks.py:49-50,133) for `count`
  * (<= 12) parameter tensors in one launch, then the soft update of the matching target tensors
