@@ -53,6 +53,10 @@ class TTTdInput(C.Structure):
                 ("y_out", C.c_void_p), ("q_out", C.c_void_p), ("step_dev", C.c_void_p)]
 
 
+class TTDqdaInput(C.Structure):
+    _fields_ = [("critic", C.POINTER(TTMlpWeights)), ("q_out", C.c_void_p), ("dq_da", C.c_void_p)]
+
+
 class TTMlpBwdWs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dpre", "dz", "dx2", "dy1", "dx1")]
 
@@ -99,11 +103,11 @@ _SIGNATURES = {
     "tt_critic_head_td": (C.c_int, [_I, _P, _P, C.POINTER(TTMlpWeights), _P, _P, C.c_float, _P, _P, _P, _P]),
     "tt_mlp_backward": (C.c_int, [_I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, C.POINTER(TTMlpWeights),
                                   C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights), C.POINTER(TTTdInput),
-                                  _P]),
+                                  C.POINTER(TTDqdaInput), _P]),
     "tt_mlp_backward_adam": (C.c_int, [_I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, C.POINTER(TTMlpWeights),
                                        C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights), _I, _P, _P, _P,
                                        _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
-                                       C.POINTER(TTTdInput), _P]),
+                                       C.POINTER(TTTdInput), C.POINTER(TTDqdaInput), _P]),
     "tt_adam_soft_update": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                       C.c_float, C.c_float, _P]),
     "tt_td_target": (C.c_int, [_I, _P, _P, _P, C.c_float, _P, _P, _P]),

@@ -416,14 +416,13 @@ struct TdIn {
 };
 
 template <bool CRITIC>
-__global__ __launch_bounds__(64 * NW) void k_bwd_rows(const int n, const int mode, const float scale,
-                                                      const float *__restrict__ d_out, const float *__restrict__ out,
-                                                      const float *__restrict__ y, const float *__restrict__ aux,
-                                                      const Weights W, const Saved sv, const BwdOut o, const TdIn td) {
-    __shared__ __attribute__((aligned(16))) float dx2_s[TR * DS];    // [16][308]
-    __shared__ float red[NW * TR];
+__device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const float scale,
+                                              const float *__restrict__ d_out, const float *__restrict__ out,
+                                              const float *__restrict__ y, const float *__restrict__ aux,
+                                              const Weights &W, const Saved &sv, const BwdOut &o, const TdIn &td,
+                                              float *__restrict__ dx2_s, float *__restrict__ red, const int row0) {
+    // dx2_s [16][308]: A operand of phase B; red [NW][16]: cross-wave reductions
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-    const int row0 = blockIdx.x * TR;
     STAMP(8);
     // ---- phase A: head, ReLU and LayerNorm2 backward; wave w owns rows 2w, 2w+1; lanes stride the 300 columns
 #pragma unroll
@@ -564,6 +563,34 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows(const int n, const int mod
         }
     }
     STAMP(11);
+}
+
+template <bool CRITIC>
+__global__ __launch_bounds__(64 * NW) void k_bwd_rows(const int n, const int mode, const float scale,
+                                                      const float *__restrict__ d_out, const float *__restrict__ out,
+                                                      const float *__restrict__ y, const float *__restrict__ aux,
+                                                      const Weights W, const Saved sv, const BwdOut o, const TdIn td) {
+    __shared__ __attribute__((aligned(16))) float dx2_s[TR * DS];
+    __shared__ float red[NW * TR];
+    bwd_rows_body<CRITIC>(n, mode, scale, d_out, out, y, aux, W, sv, o, td, dx2_s, red, blockIdx.x * TR);
+}
+
+// The actor's step through the updated critic (DDPG_agent.py:100-103) for the 16 rows of a workgroup in ONE launch:
+// Q(s, mu(s)) with dQ/da on the critic (forward only), then the actor's per-row backward with d(loss)/d(mu) =
+// scale * dQ/da.  Both halves partition the batch by the same rows, so nothing crosses workgroups between them.
+__global__ __launch_bounds__(64 * NW) void k_actor_rows(const int n, const float scale, const float *__restrict__ obs,
+                                                    const float *__restrict__ mu, const Weights Wc, float *__restrict__ q_out,
+                                                    float *__restrict__ dq_da, const Weights Wa, const Saved sv_actor,
+                                                    const BwdOut o) {
+    __shared__ __attribute__((aligned(16))) float tile[TR * HS1];       // h1 tile of the forward, then dX2 tile of the backward
+    __shared__ float red[NW * TR];
+    static_assert(TR * DS <= TR * HS1, "the backward's tile must fit in the forward's");
+    const int row0 = blockIdx.x * TR;
+    const Saved none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    fwd_small_body<true>(n, obs, mu, Wc, q_out, none, dq_da, nullptr, tile, red, row0);
+    __syncthreads();                                   // dq_da of these rows (global) and the tile are handed over
+    const TdIn td{};
+    bwd_rows_body<false>(n, 2, scale, nullptr, mu, nullptr, dq_da, Wa, sv_actor, o, td, tile, red, row0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -946,10 +973,11 @@ int tt_critic_head_td(int n, const float *z_state, const float *action, const tt
 static int backward_impl(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
                          const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
                          const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const AdamFused &A,
-                         const tt_td_input *tdi, tt_stream_t stream) {
+                         const tt_td_input *tdi, const tt_dqda_input *dqi, tt_stream_t stream) {
     if (n <= 0 || !obs || !out || !ok_shape(w, critic != 0) || !ok_shape(grads, critic != 0) || !saved || !ws ||
-        (critic && !action) || mode < 0 || mode > 2 || (mode == 0 && !d_out) || (mode == 1 && !y && !tdi) || (mode == 2 && !aux))
+        (critic && !action) || mode < 0 || mode > 2 || (mode == 0 && !d_out) || (mode == 1 && !y && !tdi) || (mode == 2 && !aux && !dqi))
         return TT_EINVAL;
+    if (dqi && (critic || mode != 2 || !ok_shape(dqi->critic, true) || !dqi->q_out || !dqi->dq_da)) return TT_EINVAL;
     TdIn td{};
     if (tdi) {
         const tt_mlp_weights *tw = tdi->target_critic;
@@ -968,6 +996,9 @@ static int backward_impl(int n, int critic, int mode, float scale, const float *
     if (critic)
         hipLaunchKernelGGL(k_bwd_rows<true>, grid, block_rows, 0, stream, n, mode, scale, d_out, out, y, aux,
                            to_weights(w), sv, o, td);
+    else if (dqi)
+        hipLaunchKernelGGL(k_actor_rows, grid, block_rows, 0, stream, n, scale, obs, out, to_weights(dqi->critic), dqi->q_out,
+                           dqi->dq_da, to_weights(w), sv, o);
     else
         hipLaunchKernelGGL(k_bwd_rows<false>, grid, block_rows, 0, stream, n, mode, scale, d_out, out, y, aux,
                            to_weights(w), sv, o, td);
@@ -984,9 +1015,9 @@ static int backward_impl(int n, int critic, int mode, float scale, const float *
 int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
                     const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
                     const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const tt_td_input *td,
-                    tt_stream_t stream) {
+                    const tt_dqda_input *dq, tt_stream_t stream) {
     AdamFused A{};
-    return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, td, stream);
+    return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, td, dq, stream);
 }
 
 int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
@@ -994,7 +1025,7 @@ int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *
                          const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, int count,
                          float *const *params, float *const *exp_avg, float *const *exp_avg_sq, float *const *targets,
                          const int64_t *step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
-                         float tau, const tt_td_input *td, tt_stream_t stream) {
+                         float tau, const tt_td_input *td, const tt_dqda_input *dq, tt_stream_t stream) {
     if (count != (critic ? 12 : 10) || !params || !exp_avg || !exp_avg_sq || !step_dev) return TT_EINVAL;
     AdamFused A{};
     for (int i = 0; i < count; ++i) {
@@ -1004,7 +1035,7 @@ int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *
     A.step_dev = reinterpret_cast<const long long *>(step_dev);
     A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.weight_decay = weight_decay; A.tau = tau;
     A.on = 1;
-    return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, td, stream);
+    return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, td, dq, stream);
 }
 
 int tt_adam_soft_update(int count, float *const *params, const float *const *grads, float *const *exp_avg,

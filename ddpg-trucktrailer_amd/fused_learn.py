@@ -93,20 +93,21 @@ class FusedLearner:
                                              C.byref(fused.weights_of(net)), _p(out), C.byref(saved) if saved else None,
                                              _p(dq_da), self._stream()))
 
-    def _bwd(self, st, mode, scale, obs, action, out, y=None, aux=None, td=None):
+    def _bwd(self, st, mode, scale, obs, action, out, y=None, aux=None, td=None, dq=None):
         L.check(self.lib.tt_mlp_backward(self.B, 1 if st.critic else 0, mode, float(scale), _p(obs), _p(action), None,
                                          _p(out), _p(y), _p(aux), C.byref(fused.weights_of(st.net)), C.byref(st.saved),
                                          C.byref(self.ws), C.byref(st.gstruct), C.byref(td) if td is not None else None,
-                                         self._stream()))
+                                         C.byref(dq) if dq is not None else None, self._stream()))
 
-    def _bwd_adam(self, st, hyp, tau, mode, scale, obs, action, out, y=None, aux=None, td=None):
+    def _bwd_adam(self, st, hyp, tau, mode, scale, obs, action, out, y=None, aux=None, td=None, dq=None):
         """_bwd + _adam in the backward's own two launches (include/ttenv.h: tt_mlp_backward_adam)."""
         lr, b1, b2, eps, wd = hyp
         L.check(self.lib.tt_mlp_backward_adam(self.B, 1 if st.critic else 0, mode, float(scale), _p(obs), _p(action), None,
                                               _p(out), _p(y), _p(aux), C.byref(fused.weights_of(st.net)),
                                               C.byref(st.saved), C.byref(self.ws), C.byref(st.gstruct), st.count, st.a_p,
                                               st.a_m, st.a_v, st.a_t, _p(self.step_dev), lr, b1, b2, eps, wd, tau,
-                                              C.byref(td) if td is not None else None, self._stream()))
+                                              C.byref(td) if td is not None else None,
+                                              C.byref(dq) if dq is not None else None, self._stream()))
 
     def _adam(self, st, hyp, tau):
         lr, b1, b2, eps, wd = hyp
@@ -169,11 +170,12 @@ class FusedLearner:
         ag, B = self.agent, self.B
         if separate_adam:
             self._adam(self.critic, self.hyp_critic, ag.tau)
-        self._fwd(ag.critic, states, self.mu, self.q_pi, None, self.dq_da)
+        # Q(s, mu(s)) with dQ/da and the actor's per-row backward share one launch (tt_dqda_input): same row partition
+        dq = L.TTDqdaInput(critic=C.pointer(fused.weights_of(ag.critic)), q_out=self.q_pi.data_ptr(), dq_da=self.dq_da.data_ptr())
         if separate_adam:
-            self._bwd(self.actor, 2, -1.0 / B, states, None, self.mu, aux=self.dq_da)
+            self._bwd(self.actor, 2, -1.0 / B, states, None, self.mu, dq=dq)
         else:
-            self._bwd_adam(self.actor, self.hyp_actor, ag.tau, 2, -1.0 / B, states, None, self.mu, aux=self.dq_da)
+            self._bwd_adam(self.actor, self.hyp_actor, ag.tau, 2, -1.0 / B, states, None, self.mu, dq=dq)
 
     def phase_c(self):
         self._adam(self.actor, self.hyp_actor, self.agent.tau)

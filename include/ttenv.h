@@ -289,10 +289,17 @@ typedef struct tt_td_input {
     float *y_out, *q_out;
     int64_t *step_dev;
 } tt_td_input;
+/* dq (optional, actor with mode 2 only; aux may then be NULL): the critic forward that produces aux = dQ/da done in the
+ * actor's per-row backward launch -- Q(s, out) on `critic` for the same rows (DDPG_agent.py:101-102), q_out [n] and
+ * dq_da [n] written out, then the backward with d(loss)/d(out) = scale * dq_da. */
+typedef struct tt_dqda_input {
+    const tt_mlp_weights *critic;
+    float *q_out, *dq_da;
+} tt_dqda_input;
 int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
                     const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
                     const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const tt_td_input *td,
-                    tt_stream_t stream);
+                    const tt_dqda_input *dq, tt_stream_t stream);
 
 /* tt_mlp_backward with the optimizer step of tt_adam_soft_update applied in the weight-gradient launch itself (each
  * gradient element is finished by exactly one workgroup, which then updates that parameter, its Adam moments and its
@@ -304,7 +311,7 @@ int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *
                          const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, int count,
                          float *const *params, float *const *exp_avg, float *const *exp_avg_sq, float *const *targets,
                          const int64_t *step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
-                         float tau, const tt_td_input *td, tt_stream_t stream);
+                         float tau, const tt_td_input *td, const tt_dqda_input *dq, tt_stream_t stream);
 
 /* optimizer.step() of torch.optim.Adam (weight decay folded into the gradient; networks.py:49-50,133) for `count`
  * (<= 12) parameter tensors in one launch, then the soft update of the matching target tensors

@@ -50,7 +50,7 @@ def test_forward_save_and_backward_match_autograd(gpu_device, B):
         if act is not None:
             assert (dq_da - torch.autograd.grad(net(s, a_req).sum(), a_req)[0].view(-1)).abs().max().item() <= 2e-5
         L.check(lib.tt_mlp_backward(B, 1 if act is not None else 0, 0, 1.0, _p(s), _p(act), _p(d_out), _p(out), None, None,
-                                    C.byref(fused.weights_of(net)), C.byref(st.saved), C.byref(ws), C.byref(st.gstruct), None, stream))
+                                    C.byref(fused.weights_of(net)), C.byref(st.saved), C.byref(ws), C.byref(st.gstruct), None, None, stream))
         for p, gk in zip(st.params, st.grads):
             scale = max(1e-3, p.grad.abs().max().item())
             assert (gk - p.grad).abs().max().item() <= 3e-5 * scale + 1e-6, (tuple(p.shape), (gk - p.grad).abs().max().item(), scale)
