@@ -1,16 +1,22 @@
 // ttlearn.hip -- hand-fused DDPG learn() for the reference-shaped networks (23 -> 400 -> LN -> ReLU -> 300 -> LN ...),
 // exact f32, MI355X (gfx950).  What DDPG_agent.learn() (DDPG/DDPG_agent.py:72-106) does through ~140 autograd
-// kernels at batch 256 is done here in about a dozen launches:
+// kernels at batch 256 is done here in six launches (sample -- csrc/ttnet.hip -- then):
 //
-//   k_fwd_small<CRITIC>   forward of one net on the batch, saving what its backward needs (normalised
-//                         pre-activations, 1/sigma, post-ReLU activations); for the critic optionally dQ/da
-//   k_bwd_rows<CRITIC>    per-row backward: head -> ReLU -> LayerNorm2 -> dH1 = dX2 * W2 (MFMA) -> ReLU -> LayerNorm1
+//   k_fwd_multi           learn()'s first phase: up to four forwards in one launch (target actor and the target critic's
+//                         state branch on s', Q(s,a) and mu(s) with what their backward needs: normalised
+//                         pre-activations, 1/sigma, post-ReLU activations); k_fwd_small<CRITIC> is one of them alone
+//   k_bwd_rows<CRITIC>    per-row backward: [critic: q' and the TD target for its rows ->] head -> ReLU -> LayerNorm2 ->
+//                         dH1 = dX2 * W2 (MFMA) -> ReLU -> LayerNorm1
 //   k_bwd_weights         dW2 = dX2^T * H1 and dW1 = dX1^T * S on the MFMA (K = batch), all bias / LayerNorm / head
-//                         gradients as deterministic column sums (no atomics)
-//   k_adam_soft           torch.optim.Adam's update (L2 weight decay in the gradient) + the soft target update
+//                         gradients as deterministic column sums (no atomics), then (one rank) torch.optim.Adam's
+//                         update + the soft target update on each element just finished
+//   k_actor_rows          the actor's step through the updated critic for a workgroup's rows: Q(s, mu(s)) with dQ/da
+//                         (critic forward), then the actor's per-row backward
+//   k_adam_soft           Adam + soft update as a launch of its own (data-parallel ranks: after the all-reduce);
+//   k_head_td, k_td_target  the TD target as launches of their own
 //
-// Small-batch geometry: a workgroup owns 16 rows; its 4 waves split the output COLUMNS (so a 256-row batch is 16
-// workgroups x 4 waves instead of 4 x 4), and LayerNorm statistics are combined across the waves through LDS.
+// Small-batch geometry: a workgroup owns 16 rows; its 8 waves split the output COLUMNS (so a 256-row batch is 16
+// workgroups x 8 waves), and LayerNorm statistics are combined across the waves through LDS.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

@@ -1,5 +1,6 @@
-"""FusedLearner: Agent.learn() (DDPG/DDPG_agent.py:72-106) as ~12 hand-written HIP launches (csrc/ttlearn.hip)
-instead of ~140 autograd kernels, for the reference-shaped networks (23-400-300-1, LayerNorm) on a GPU.
+"""FusedLearner: Agent.learn() (DDPG/DDPG_agent.py:72-106) as five hand-written HIP launches after the sampling one
+(csrc/ttlearn.hip) instead of ~140 autograd kernels, for the reference-shaped networks (23-400-300-1, LayerNorm) on a
+GPU; with data-parallel ranks, eight launches and the two gradient all-reduces.
 
 Same order of operations as the reference: TD target from the target nets -> critic MSE step -> actor step through
 the ALREADY UPDATED critic -> soft update of both targets.  Same optimizer arithmetic (torch.optim.Adam with the
