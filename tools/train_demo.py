@@ -2,7 +2,7 @@
 """GPU: an actual training run of the N-env DDPG loop (the reference's hyper-parameters, trainv2.py:404-407), to see the
 policy improve: mean reward per env-step, episodes finished, share of them that reach the goal (final reward > 150: the
 +200 success bonus of reward_functionv1.py:466-470 is the only way to get there), per block of vector steps.
-Usage: train_demo.py [n_envs] [vector_steps] [report_every]"""
+Usage: train_demo.py [n_envs] [vector_steps] [report_every] [ring_slots] [batch]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,14 +13,15 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 total = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
 every = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
 ring_slots = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+batch = int(sys.argv[5]) if len(sys.argv) > 5 else 256
 env = TruckTrailerVecEnv(n)
 env.reset(seed=27)
-loop = DDPGRollout(env, batch_size=256, replay_slots=ring_slots, seed=27, fused_learn=os.environ.get('TT_TORCH_LEARN') != '1')
+loop = DDPGRollout(env, batch_size=batch, replay_slots=ring_slots, seed=27, fused_learn=os.environ.get('TT_TORCH_LEARN') != '1')
 loop.prepare()
 slots = loop.ring.slots
 t0 = time.time()
 done_steps = 0
-print(f"N = {n}, batch 256, alpha 1e-4, beta 1e-3, tau 1e-3, gamma 0.99, OU(0.2, 0.15, 0.01); one learn() per vector step")
+print(f"N = {n}, batch {batch}, alpha 1e-4, beta 1e-3, tau 1e-3, gamma 0.99, OU(0.2, 0.15, 0.01); one learn() per vector step")
 print("vector steps | env-steps | mean reward/step | episodes ended | reached goal | jackknife-like (r < -400) | s")
 while done_steps < total:
     block_r = torch.zeros((), device=env.device, dtype=torch.float64)
