@@ -21,6 +21,11 @@ from ddpg_trucktrailer_amd.noise import VecOUNoise
 from ddpg_trucktrailer_amd.replay_buffer import TrajectoryRing
 
 
+# every launch of a capture comes from the capturing thread; "thread_local" keeps another thread's runtime calls (the
+# collective library's watchdog, a data loader) from invalidating it
+_CAPTURE_MODE = "thread_local"
+
+
 class DDPGRollout:
     def __init__(self, env, batch_size=256, replay_slots=64, seed=27, alpha=1e-4, beta=1e-3, tau=1e-3, gamma=0.99,
                  fc1_dims=400, fc2_dims=300, world_size=1, use_graph=True, agent=None, fused_learn=True, graph_steps=4):
@@ -109,7 +114,7 @@ class DDPGRollout:
                     self._learn_once()
             side.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=side):
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode=_CAPTURE_MODE):
                 self._learn_once()
             torch.cuda.current_stream().wait_stream(side)
         self.graph.replay()
@@ -138,7 +143,7 @@ class DDPGRollout:
         self.step_graphs = []
         for c in range(ring.slots // G):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode=_CAPTURE_MODE):
                 for i in range(G):
                     self._act_and_step(ring.slots + c * G + i)      # + slots: any k > 0 with this ring position
                     if self.dp:                                     # up to the critic's gradient; see _dp_step
@@ -152,7 +157,7 @@ class DDPGRollout:
             self.dp_graphs = []
             for fn in (lambda: self.learner.phase_b(s, separate_adam=True), self.learner.phase_c):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
+                with torch.cuda.graph(g, stream=side, capture_error_mode=_CAPTURE_MODE):
                     fn()
                 self.dp_graphs.append(g)
         torch.cuda.current_stream().wait_stream(side)
