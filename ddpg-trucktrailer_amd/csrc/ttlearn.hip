@@ -34,6 +34,9 @@ constexpr int NW = 8;                     // waves per workgroup: two per SIMD, 
 constexpr int HS1 = 404;                  // LDS row stride of the 16 x 400 activation tile: 16-byte rows, and 404 mod 64 = 20
                                           // spreads the 16 rows of a ds_read_b128 fragment over all 64 banks
 
+constexpr int DS = 308;                  // LDS row stride of the 16 x 300 tiles (fc2 pre-activations; dX2 as the A operand
+                                          // with K = 304): 16-byte rows
+
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 #ifdef TT_STAMPS   // diagnostic build only: wall-clock stamps (100 MHz) of workgroup 0 / wave 0 at phase boundaries
@@ -59,12 +62,26 @@ struct Saved {          // forward activations kept for the backward (all [B, .]
     float *__restrict__ rstd1, *__restrict__ rstd2;   // [B]
 };
 
+// Reductions on the DPP path (VALU speed) instead of __shfl_xor, which hipcc turns into ds_bpermute: an LDS round trip
+// (~100 cycles) per step, and these sums sit on the critical path of every row phase.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row (= the lanes that share lane >> 4); every lane of the row gets it
 __device__ __forceinline__ float row_sum16(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    v += dpp_f<0xB1>(v);       // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_f<0x4E>(v);       // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_f<0x141>(v);      // row_half_mirror: the other quad of the half row
+    v += dpp_f<0x140>(v);      // row_mirror: the other half row
     return v;
+}
+
+// sum over the wave; the result is wave-uniform
+__device__ __forceinline__ float wave_sum64(float v) {
+    const int u = __builtin_bit_cast(int, row_sum16(v));
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48)));
 }
 
 // combine a per-wave, per-row partial (valid in every lane of the 16-lane group of that row) across the 4 waves.
@@ -106,28 +123,32 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
                                                const float *__restrict__ action, const Weights &W,
                                                float *__restrict__ out, const Saved &sv, float *__restrict__ dq_da,
                                                float *__restrict__ z_state, float *__restrict__ h1_s,
-                                               float *__restrict__ red, const int row0) {
-    // h1_s [16][404]: A operand of layer 2; red [NW][16]: cross-wave reductions
+                                               float *__restrict__ z_s, const int row0) {
+    // h1_s [16][404]: fc1 pre-activations, then the A operand of layer 2; z_s [16][308]: fc2 pre-activations.
+    // The two products split the COLUMNS over the 8 waves; everything per row (both LayerNorms, the head) is done by the
+    // wave that owns the row (wave w: rows 2w, 2w+1; lanes stride the columns) after ONE hand-over through LDS, with
+    // wave-level reductions: 4 barriers per forward instead of 13, and the saved activations leave as whole rows.
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
 
     STAMP(0);
     constexpr int MT1 = (NT1 + NW - 1) / NW, MT2 = (NT2 + NW - 1) / NW;
-    // every per-column vector this lane will need, loaded NOW: the uses sit behind barriers (the cross-wave LayerNorm
-    // reductions), which the compiler cannot move a load across, so each would cost an exposed L2 round trip there
-    float pb1[MT1], pg1[MT1], pbe1[MT1], pb2[MT2], pg2[MT2], pbe2[MT2], pw3[MT2], pwa[MT2], pba[MT2];
+    constexpr int C1 = (H1 + 63) / 64, C2 = (H2 + 63) / 64;     // columns per lane in the row phases: 7 and 5
+    // every per-column vector this lane will need, loaded NOW: the uses sit behind barriers, which the compiler cannot
+    // move a load across, so each would cost an exposed L2 round trip there
+    float pb1[C1], pg1[C1], pbe1[C1], pb2[C2], pg2[C2], pbe2[C2], pw3[C2], pwa[C2], pba[C2];
 #pragma unroll
-    for (int i = 0; i < MT1; ++i) {
-        const int t = wave + NW * i, col = t * 16 + l15;
-        const bool real = t < NT1;
-        pb1[i] = real ? W.b1[col] : 0.f; pg1[i] = real ? W.g1[col] : 0.f; pbe1[i] = real ? W.be1[col] : 0.f;
+    for (int i = 0; i < C1; ++i) {
+        const int c = lane + 64 * i;
+        const bool real = c < H1;
+        pb1[i] = real ? W.b1[c] : 0.f; pg1[i] = real ? W.g1[c] : 0.f; pbe1[i] = real ? W.be1[c] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < MT2; ++i) {
-        const int col = (wave + NW * i) * 16 + l15;
-        const bool real = wave + NW * i < NT2 && col < H2;
-        pb2[i] = real ? W.b2[col] : 0.f; pg2[i] = real ? W.g2[col] : 0.f; pbe2[i] = real ? W.be2[col] : 0.f;
-        pw3[i] = real ? W.w3[col] : 0.f;
-        pwa[i] = (CRITIC && real) ? W.wa[col] : 0.f; pba[i] = (CRITIC && real) ? W.ba[col] : 0.f;
+    for (int i = 0; i < C2; ++i) {
+        const int c = lane + 64 * i;
+        const bool real = c < H2;
+        pb2[i] = real ? W.b2[c] : 0.f; pg2[i] = real ? W.g2[c] : 0.f; pbe2[i] = real ? W.be2[c] : 0.f;
+        pw3[i] = real ? W.w3[c] : 0.f;
+        pwa[i] = (CRITIC && real) ? W.wa[c] : 0.f; pba[i] = (CRITIC && real) ? W.ba[c] : 0.f;
     }
     // ---- layer 1 (K = 23): operands straight from global; this wave's column tiles t = wave, wave+NW, ...
     f32x4 acc1[MT1];
@@ -156,54 +177,46 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
         }
     }
     STAMP(1);
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    // accumulator element [i][r] is row l4*4 + r, column (wave + NW*i)*16 + l15
 #pragma unroll
     for (int i = 0; i < MT1; ++i) {
         const int t = wave + NW * i;
         if (t < NT1) {
-            const float bias = pb1[i];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { acc1[i][r] += bias; s[r] += acc1[i][r]; }
+            for (int r = 0; r < 4; ++r) h1_s[(l4 * 4 + r) * HS1 + t * 16 + l15] = acc1[i][r];
         }
     }
+    __syncthreads();
+    // bias, LayerNorm(400) (biased variance, eps 1e-5), ReLU for this wave's two rows
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s[r] = row_sum16(s[r]);
-    cross_wave_sum(red, wave, l4, l15, s);
-    float mean[4], rstd[4], ss[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int rr = 0; rr < TR / NW; ++rr) {
+        const int lr = wave * (TR / NW) + rr, row = row0 + lr;
+        float x[C1], s1 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) mean[r] = s[r] * (1.f / H1);
-#pragma unroll
-    for (int i = 0; i < MT1; ++i) {
-        if (wave + NW * i < NT1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float d = acc1[i][r] - mean[r]; ss[r] = fmaf(d, d, ss[r]); }
+        for (int i = 0; i < C1; ++i) {
+            const int c = lane + 64 * i;
+            x[i] = c < H1 ? h1_s[lr * HS1 + c] + pb1[i] : 0.f;
+            s1 += x[i];
         }
-    }
+        const float mean = wave_sum64(s1) * (1.f / H1);
+        float ss = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ss[r] = row_sum16(ss[r]);
-    cross_wave_sum(red, wave, l4, l15, ss);
+        for (int i = 0; i < C1; ++i) {
+            const float d = lane + 64 * i < H1 ? x[i] - mean : 0.f;
+            ss = fmaf(d, d, ss);
+        }
+        const float rstd = rsqrtf(wave_sum64(ss) * (1.f / H1) + 1e-5f);
+        if (sv.rstd1 && lane == 0 && row < n) sv.rstd1[row] = rstd;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rstd[r] = rsqrtf(ss[r] * (1.f / H1) + 1e-5f);
-    if (sv.rstd1 && wave == 0 && l15 == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (row0 + l4 * 4 + r < n) sv.rstd1[row0 + l4 * 4 + r] = rstd[r];
-    }
-#pragma unroll
-    for (int i = 0; i < MT1; ++i) {
-        const int t = wave + NW * i;
-        if (t < NT1) {
-            const int col = t * 16 + l15;
-            const float g = pg1[i], be = pbe1[i];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lr = l4 * 4 + r;
-                const float xh = (acc1[i][r] - mean[r]) * rstd[r];
-                const float h = fmaxf(fmaf(xh, g, be), 0.f);
-                h1_s[lr * HS1 + col] = h;
-                if (sv.xh1 && row0 + lr < n) {
-                    sv.xh1[(size_t)(row0 + lr) * H1 + col] = xh;
-                    sv.h1[(size_t)(row0 + lr) * H1 + col] = h;
+        for (int i = 0; i < C1; ++i) {
+            const int c = lane + 64 * i;
+            if (c < H1) {
+                const float xh = (x[i] - mean) * rstd;
+                const float h = fmaxf(fmaf(xh, pg1[i], pbe1[i]), 0.f);
+                h1_s[lr * HS1 + c] = h;
+                if (sv.xh1 && row < n) {
+                    sv.xh1[(size_t)row * H1 + c] = xh;
+                    sv.h1[(size_t)row * H1 + c] = h;
                 }
             }
         }
@@ -247,103 +260,71 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
     }
 
     STAMP(3);
-    // ---- epilogue
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT2; ++i) {
-        const int col = (wave + NW * i) * 16 + l15;
-        const bool real = wave + NW * i < NT2 && col < H2;
-        const float bias = pb2[i];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { acc2[i][r] = real ? acc2[i][r] + bias : 0.f; s[r] += acc2[i][r]; }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s[r] = row_sum16(s[r]);
-    cross_wave_sum(red, wave, l4, l15, s);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { mean[r] = s[r] * (1.f / H2); ss[r] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < MT2; ++i) {
-        const bool real = wave + NW * i < NT2 && (wave + NW * i) * 16 + l15 < H2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float d = real ? acc2[i][r] - mean[r] : 0.f; ss[r] = fmaf(d, d, ss[r]); }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ss[r] = row_sum16(ss[r]);
-    cross_wave_sum(red, wave, l4, l15, ss);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) rstd[r] = rsqrtf(ss[r] * (1.f / H2) + 1e-5f);
-    if (sv.rstd2 && wave == 0 && l15 == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (row0 + l4 * 4 + r < n) sv.rstd2[row0 + l4 * 4 + r] = rstd[r];
-    }
-    float av[4] = {0.f, 0.f, 0.f, 0.f};
-    if (CRITIC && z_state) {
-        // state branch only (networks.py:55-61): z_state [B,300] = bn2(fc2(relu(bn1(fc1(s))))) before the action enters;
-        // k_head_td finishes q once the action is known, so this pass can run NEXT TO the actor pass that produces it
-#pragma unroll
-        for (int i = 0; i < MT2; ++i) {
-            const int col = (wave + NW * i) * 16 + l15;
-            if (wave + NW * i < NT2 && col < H2) {
-                const float g = pg2[i], be = pbe2[i];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = row0 + l4 * 4 + r;
-                    if (row < n) z_state[(size_t)row * H2 + col] = fmaf((acc2[i][r] - mean[r]) * rstd[r], g, be);
-                }
-            }
-        }
-        return;
-    }
-    if (CRITIC) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + l4 * 4 + r;
-            av[r] = row < n ? action[row] : 0.f;
-        }
-    }
-    float dot[4] = {0.f, 0.f, 0.f, 0.f}, dqa[4] = {0.f, 0.f, 0.f, 0.f};
+    // ---- hand the fc2 pre-activations over (columns 300..319 of the last tile are padding)
 #pragma unroll
     for (int i = 0; i < MT2; ++i) {
         const int col = (wave + NW * i) * 16 + l15;
         if (wave + NW * i < NT2 && col < H2) {
-            const float g = pg2[i], be = pbe2[i], w3 = pw3[i], wa = pwa[i], ba = pba[i];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lr = l4 * 4 + r;
-                const float xh = (acc2[i][r] - mean[r]) * rstd[r];
-                float z = fmaf(xh, g, be);
-                if (CRITIC) z += fmaf(av[r], wa, ba);
+            for (int r = 0; r < 4; ++r) z_s[(l4 * 4 + r) * DS + col] = acc2[i][r];
+        }
+    }
+    __syncthreads();
+    // ---- epilogue for this wave's two rows: bias, LayerNorm(300), (critic: + action_value(a)), ReLU, head
+#pragma unroll
+    for (int rr = 0; rr < TR / NW; ++rr) {
+        const int lr = wave * (TR / NW) + rr, row = row0 + lr;
+        float x[C2], s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < C2; ++i) {
+            const int c = lane + 64 * i;
+            x[i] = c < H2 ? z_s[lr * DS + c] + pb2[i] : 0.f;
+            s1 += x[i];
+        }
+        const float mean = wave_sum64(s1) * (1.f / H2);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < C2; ++i) {
+            const float d = lane + 64 * i < H2 ? x[i] - mean : 0.f;
+            ss = fmaf(d, d, ss);
+        }
+        const float rstd = rsqrtf(wave_sum64(ss) * (1.f / H2) + 1e-5f);
+        if (sv.rstd2 && lane == 0 && row < n) sv.rstd2[row] = rstd;
+        if (CRITIC && z_state) {
+            // state branch only (networks.py:55-61): z_state [B,300] = bn2(fc2(relu(bn1(fc1(s))))) before the action
+            // enters; the TD prologue of the critic's backward (or k_head_td) finishes q once the action is known, so
+            // this pass can run NEXT TO the actor pass that produces it
+#pragma unroll
+            for (int i = 0; i < C2; ++i) {
+                const int c = lane + 64 * i;
+                if (c < H2 && row < n) z_state[(size_t)row * H2 + c] = fmaf((x[i] - mean) * rstd, pg2[i], pbe2[i]);
+            }
+            continue;
+        }
+        const float av = (CRITIC && row < n) ? action[row] : 0.f;
+        float dot = 0.f, dqa = 0.f;
+#pragma unroll
+        for (int i = 0; i < C2; ++i) {
+            const int c = lane + 64 * i;
+            if (c < H2) {
+                const float xh = (x[i] - mean) * rstd;
+                float z = fmaf(xh, pg2[i], pbe2[i]);
+                if (CRITIC) z += fmaf(av, pwa[i], pba[i]);
                 const float h = fmaxf(z, 0.f);
-                dot[r] = fmaf(h, w3, dot[r]);
-                if (CRITIC) dqa[r] = fmaf(z > 0.f ? w3 : 0.f, wa, dqa[r]);
-                if (sv.xh2 && row0 + lr < n) {
-                    sv.xh2[(size_t)(row0 + lr) * H2 + col] = xh;
-                    sv.h2[(size_t)(row0 + lr) * H2 + col] = h;
+                dot = fmaf(h, pw3[i], dot);
+                if (CRITIC) dqa = fmaf(z > 0.f ? pw3[i] : 0.f, pwa[i], dqa);
+                if (sv.xh2 && row < n) {
+                    sv.xh2[(size_t)row * H2 + c] = xh;
+                    sv.h2[(size_t)row * H2 + c] = h;
                 }
             }
         }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dot[r] = row_sum16(dot[r]);
-    cross_wave_sum(red, wave, l4, l15, dot);
-    if (CRITIC && dq_da) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dqa[r] = row_sum16(dqa[r]);
-        cross_wave_sum(red, wave, l4, l15, dqa);
-    }
-    if (wave == 0 && l15 == 0) {
-        const float b3 = W.b3[0];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + l4 * 4 + r;
-            if (row < n) {
-                const float v = dot[r] + b3;
-                out[row] = CRITIC ? v : tanhf(v);
-                if (CRITIC && dq_da) dq_da[row] = dqa[r];
-            }
+        dot = wave_sum64(dot);
+        if (CRITIC && dq_da) dqa = wave_sum64(dqa);
+        if (lane == 0 && row < n) {
+            const float v = dot + W.b3[0];
+            out[row] = CRITIC ? v : tanhf(v);
+            if (CRITIC && dq_da) dq_da[row] = dqa;
         }
     }
     STAMP(4);
@@ -355,8 +336,8 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_small(const int n, const float 
                                                    float *__restrict__ out, const Saved sv, float *__restrict__ dq_da,
                                                    float *__restrict__ z_state) {
     __shared__ __attribute__((aligned(16))) float h1_s[TR * HS1];
-    __shared__ float red[NW * TR];
-    fwd_small_body<CRITIC>(n, obs, action, W, out, sv, dq_da, z_state, h1_s, red, blockIdx.x * TR);
+    __shared__ __attribute__((aligned(16))) float z_s[TR * DS];
+    fwd_small_body<CRITIC>(n, obs, action, W, out, sv, dq_da, z_state, h1_s, z_s, blockIdx.x * TR);
 }
 
 // Up to four independent forwards on the same number of rows in ONE launch (workgroup b serves job b / blocks_per_job):
@@ -377,11 +358,11 @@ struct FwdJobs {
 };
 __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
     __shared__ __attribute__((aligned(16))) float h1_s[TR * HS1];
-    __shared__ float red[NW * TR];
+    __shared__ __attribute__((aligned(16))) float z_s[TR * DS];
     const int job = blockIdx.x / J.blocks_per_job, row0 = (blockIdx.x - job * J.blocks_per_job) * TR;
     const FwdJob &q = J.j[job];
-    if (q.critic) fwd_small_body<true>(J.n, q.obs, q.action, q.W, q.out, q.sv, q.dq_da, q.z_state, h1_s, red, row0);
-    else fwd_small_body<false>(J.n, q.obs, q.action, q.W, q.out, q.sv, nullptr, nullptr, h1_s, red, row0);
+    if (q.critic) fwd_small_body<true>(J.n, q.obs, q.action, q.W, q.out, q.sv, q.dq_da, q.z_state, h1_s, z_s, row0);
+    else fwd_small_body<false>(J.n, q.obs, q.action, q.W, q.out, q.sv, nullptr, nullptr, h1_s, z_s, row0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -392,22 +373,12 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
 // actor (CRITIC = false): `out` is mu = tanh(pre) and the head gradient is d_out * (1 - mu^2).
 // Writes dpre [B], dz [B,300] (grad at the ReLU-masked LayerNorm2 output), dx2 [B,300] (grad at fc2's output),
 // dy1 [B,400] (grad at the ReLU-masked LayerNorm1 output), dx1 [B,400] (grad at fc1's output).
-constexpr int DS = 308;                       // LDS row stride of the dX2 tile (A operand, K = 304; 16-byte rows)
 constexpr int NG = 7;                         // 64-column groups covering the 400 columns of dH1 (the last is partial)
 
 struct BwdOut {
     float *__restrict__ dpre, *__restrict__ dz, *__restrict__ dx2, *__restrict__ dy1, *__restrict__ dx1;
 };
 
-__device__ __forceinline__ float wave_sum64(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
-}
 
 // Optional prologue of the critic's backward: the rest of the TARGET critic once the target actor's action is known
 // (networks.py:62-68) and the TD target (DDPG_agent.py:89-93), for the rows this workgroup owns -- what k_head_td does
@@ -588,15 +559,15 @@ __global__ __launch_bounds__(64 * NW) void k_actor_rows(const int n, const float
                                                     const float *__restrict__ mu, const Weights Wc, float *__restrict__ q_out,
                                                     float *__restrict__ dq_da, const Weights Wa, const Saved sv_actor,
                                                     const BwdOut o) {
-    __shared__ __attribute__((aligned(16))) float tile[TR * HS1];       // h1 tile of the forward, then dX2 tile of the backward
+    __shared__ __attribute__((aligned(16))) float tile[TR * HS1];       // the forward's h1 tile
+    __shared__ __attribute__((aligned(16))) float tile2[TR * DS];       // the forward's fc2 tile, then the backward's dX2 tile
     __shared__ float red[NW * TR];
-    static_assert(TR * DS <= TR * HS1, "the backward's tile must fit in the forward's");
     const int row0 = blockIdx.x * TR;
     const Saved none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    fwd_small_body<true>(n, obs, mu, Wc, q_out, none, dq_da, nullptr, tile, red, row0);
-    __syncthreads();                                   // dq_da of these rows (global) and the tile are handed over
+    fwd_small_body<true>(n, obs, mu, Wc, q_out, none, dq_da, nullptr, tile, tile2, row0);
+    __syncthreads();                                   // dq_da of these rows (global) and the tiles are handed over
     const TdIn td{};
-    bwd_rows_body<false>(n, 2, scale, nullptr, mu, nullptr, dq_da, Wa, sv_actor, o, td, tile, red, row0);
+    bwd_rows_body<false>(n, 2, scale, nullptr, mu, nullptr, dq_da, Wa, sv_actor, o, td, tile2, red, row0);
 }
 
 // ------------------------------------------------------------------------------------------------------
