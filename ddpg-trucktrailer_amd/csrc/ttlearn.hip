@@ -271,6 +271,13 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
     }
     __syncthreads();
     // ---- epilogue for this wave's two rows: bias, LayerNorm(300), (critic: + action_value(a)), ReLU, head
+    float avs[TR / NW];                                    // loaded before the first row's stores (see k_bwd_rows, phase A)
+#pragma unroll
+    for (int rr = 0; rr < TR / NW; ++rr) {
+        const int row = row0 + wave * (TR / NW) + rr;
+        avs[rr] = (CRITIC && !z_state && row < n) ? action[row] : 0.f;
+    }
+    const float b3 = W.b3[0];
 #pragma unroll
     for (int rr = 0; rr < TR / NW; ++rr) {
         const int lr = wave * (TR / NW) + rr, row = row0 + lr;
@@ -301,7 +308,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
             }
             continue;
         }
-        const float av = (CRITIC && row < n) ? action[row] : 0.f;
+        const float av = avs[rr];
         float dot = 0.f, dqa = 0.f;
 #pragma unroll
         for (int i = 0; i < C2; ++i) {
@@ -322,7 +329,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
         dot = wave_sum64(dot);
         if (CRITIC && dq_da) dqa = wave_sum64(dqa);
         if (lane == 0 && row < n) {
-            const float v = dot + W.b3[0];
+            const float v = dot + b3;
             out[row] = CRITIC ? v : tanhf(v);
             if (CRITIC && dq_da) dq_da[row] = dqa;
         }
@@ -401,71 +408,95 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
     // dx2_s [16][308]: A operand of phase B; red [NW][16]: cross-wave reductions
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     STAMP(8);
-    // ---- phase A: head, ReLU and LayerNorm2 backward; wave w owns rows 2w, 2w+1; lanes stride the 300 columns
+    // ---- phase A: head, ReLU and LayerNorm2 backward; wave w owns rows 2w, 2w+1; lanes stride the 300 columns.
+    // Every load of both rows is issued before the first store: the outputs are plain pointers inside a struct, so the
+    // compiler must assume a store may alias a later load and would otherwise serialise the two rows' round trips.
+    constexpr int RPW = TR / NW, C2 = (H2 + 63) / 64;
+    float w3c[C2], g2c[C2], h2v[RPW][C2], xh[RPW][C2], rs[RPW], gin[RPW], yin[RPW], outv[RPW];
+    float zt[RPW][C2], wat[C2], bat[C2], w3t[C2], mut[RPW], rt[RPW], b3t = 0.f;
+    bool dt[RPW];
+    const bool with_td = CRITIC && td.z_state;               // (uniform over the launch)
 #pragma unroll
-    for (int rr = 0; rr < TR / NW; ++rr) {
-        const int lr = wave * (TR / NW) + rr, row = row0 + lr;
-        float dpre = 0.f;
-        float y_td = 0.f;
-        if (CRITIC && td.z_state) {                          // (uniform over the workgroup)
-            float dot = 0.f;
-            if (row < n) {
-                const float a = td.mu_t[row];
+    for (int i = 0; i < C2; ++i) {
+        const int c = lane + 64 * i;
+        const bool real = c < H2;
+        w3c[i] = real ? W.w3[c] : 0.f; g2c[i] = real ? W.g2[c] : 0.f;
+        wat[i] = (with_td && real) ? td.wa[c] : 0.f; bat[i] = (with_td && real) ? td.ba[c] : 0.f;
+        w3t[i] = (with_td && real) ? td.w3[c] : 0.f;
+    }
+    if (with_td) b3t = td.b3[0];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const int c = lane + 64 * i;
-                    if (c < H2)
-                        dot = fmaf(fmaxf(td.z_state[(size_t)row * H2 + c] + fmaf(a, td.wa[c], td.ba[c]), 0.f), td.w3[c], dot);
-                }
-            }
-            dot = wave_sum64(dot);
-            if (row < n) {
-                const float q = dot + td.b3[0];
-                y_td = td.done[row] ? td.r[row] : fmaf(td.gamma, q, td.r[row]);
-                if (lane == 0) {
-                    td.y_out[row] = y_td;
-                    if (td.q_out) td.q_out[row] = q;
-                }
-            }
-            if (blockIdx.x == 0 && tid == 0 && rr == 0 && td.step_dev) *td.step_dev += 1;
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int row = row0 + wave * RPW + rr;
+        const bool ok = row < n;
+        rs[rr] = ok ? sv.rstd2[row] : 0.f;
+        outv[rr] = (ok && mode != 0) || (ok && !CRITIC) ? out[row] : 0.f;
+        gin[rr] = !ok ? 0.f : (mode == 0 ? d_out[row] : (mode == 2 ? aux[row] : 0.f));
+        yin[rr] = (ok && mode == 1 && !with_td) ? y[row] : 0.f;
+        mut[rr] = (ok && with_td) ? td.mu_t[row] : 0.f;
+        rt[rr] = (ok && with_td) ? td.r[row] : 0.f;
+        dt[rr] = (ok && with_td) ? td.done[row] != 0 : false;
+#pragma unroll
+        for (int i = 0; i < C2; ++i) {
+            const int c = lane + 64 * i;
+            const bool real = ok && c < H2;
+            const size_t q = (size_t)row * H2 + c;
+            h2v[rr][i] = real ? sv.h2[q] : 0.f;
+            xh[rr][i] = real ? sv.xh2[q] : 0.f;
+            zt[rr][i] = (real && with_td) ? td.z_state[q] : 0.f;
         }
-        if (row < n) {
-            float g = mode == 0 ? d_out[row]
-                                : (mode == 1 ? scale * (out[row] - ((CRITIC && td.z_state) ? y_td : y[row])) : scale * aux[row]);
-            if (!CRITIC) { const float mu = out[row]; g *= (1.f - mu * mu); }
+    }
+    if (with_td && blockIdx.x == 0 && tid == 0 && td.step_dev) *td.step_dev += 1;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int lr = wave * RPW + rr, row = row0 + lr;
+        const bool ok = row < n;
+        float y_td = 0.f;
+        if (with_td) {
+            float dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < C2; ++i) dot = fmaf(fmaxf(zt[rr][i] + fmaf(mut[rr], wat[i], bat[i]), 0.f), w3t[i], dot);
+            const float q = wave_sum64(dot) + b3t;
+            y_td = dt[rr] ? rt[rr] : fmaf(td.gamma, q, rt[rr]);
+            if (ok && lane == 0) {
+                td.y_out[row] = y_td;
+                if (td.q_out) td.q_out[row] = q;
+            }
+        }
+        float dpre = 0.f;
+        if (ok) {
+            float g = mode == 0 ? gin[rr] : (mode == 1 ? scale * (outv[rr] - (with_td ? y_td : yin[rr])) : scale * gin[rr]);
+            if (!CRITIC) g *= (1.f - outv[rr] * outv[rr]);
             dpre = g;
         }
-        float dxh[5], xh[5], s1 = 0.f, s2 = 0.f;
+        float dxh[C2], s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < C2; ++i) {
             const int c = lane + 64 * i;
-            dxh[i] = 0.f; xh[i] = 0.f;
-            if (c < H2 && row < n) {
-                const size_t q = (size_t)row * H2 + c;
-                const float dz = sv.h2[q] > 0.f ? dpre * W.w3[c] : 0.f;
-                o.dz[q] = dz;
-                xh[i] = sv.xh2[q];
-                dxh[i] = dz * W.g2[c];
+            dxh[i] = 0.f;
+            if (c < H2 && ok) {
+                const float dz = h2v[rr][i] > 0.f ? dpre * w3c[i] : 0.f;
+                o.dz[(size_t)row * H2 + c] = dz;
+                dxh[i] = dz * g2c[i];
                 s1 += dxh[i];
-                s2 = fmaf(dxh[i], xh[i], s2);
+                s2 = fmaf(dxh[i], xh[rr][i], s2);
             }
         }
         s1 = wave_sum64(s1) * (1.f / H2);
         s2 = wave_sum64(s2) * (1.f / H2);
-        const float rs = row < n ? sv.rstd2[row] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < C2; ++i) {
             const int c = lane + 64 * i;
             if (c < DS) {
                 float v = 0.f;
-                if (c < H2 && row < n) {
-                    v = rs * (dxh[i] - s1 - xh[i] * s2);
+                if (c < H2 && ok) {
+                    v = rs[rr] * (dxh[i] - s1 - xh[rr][i] * s2);
                     o.dx2[(size_t)row * H2 + c] = v;
                 }
                 dx2_s[lr * DS + c] = v;                     // zero in the K padding (columns 300..307)
             }
         }
-        if (lane == 0 && row < n) o.dpre[row] = dpre;
+        if (lane == 0 && ok) o.dpre[row] = dpre;
     }
     __syncthreads();
     STAMP(9);
@@ -502,16 +533,22 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
     STAMP(10);
     // ---- phase C: ReLU and LayerNorm1 backward; accumulator [t][r] is row l4*4+r, column wave*64 + 4*l15 + t
     float xh1[4][4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 hv[4], xv[4];                                   // loads of all four rows first (see phase A)
+    const float4 gm = gok ? *reinterpret_cast<const float4 *>(W.g1 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float rs1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = row0 + l4 * 4 + r;
-        float4 h = make_float4(0.f, 0.f, 0.f, 0.f), x = h, gm = h;
         const bool ok = gok && row < n;
-        if (ok) {
-            h = *reinterpret_cast<const float4 *>(sv.h1 + (size_t)row * H1 + c0);
-            x = *reinterpret_cast<const float4 *>(sv.xh1 + (size_t)row * H1 + c0);
-            gm = *reinterpret_cast<const float4 *>(W.g1 + c0);
-        }
+        hv[r] = ok ? *reinterpret_cast<const float4 *>(sv.h1 + (size_t)row * H1 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xv[r] = ok ? *reinterpret_cast<const float4 *>(sv.xh1 + (size_t)row * H1 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rs1[r] = ok ? sv.rstd1[row] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + l4 * 4 + r;
+        const float4 h = hv[r], x = xv[r];
+        const bool ok = gok && row < n;
         const float hh[4] = {h.x, h.y, h.z, h.w}, xx[4] = {x.x, x.y, x.z, x.w}, gg[4] = {gm.x, gm.y, gm.z, gm.w};
         float dy[4];
 #pragma unroll
@@ -532,7 +569,7 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
     for (int r = 0; r < 4; ++r) {
         const int row = row0 + l4 * 4 + r;
         if (gok && row < n) {
-            const float rs = sv.rstd1[row], m1 = s1[r] * (1.f / H1), m2 = s2[r] * (1.f / H1);
+            const float rs = rs1[r], m1 = s1[r] * (1.f / H1), m2 = s2[r] * (1.f / H1);
             float v[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[t] = rs * (acc[t][r] - m1 - xh1[t][r] * m2);

@@ -29,12 +29,17 @@ constexpr int BM = 64, WROWS = 16;      // rows per workgroup / per wave
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-// sum over the 16 lanes that share (lane >> 4): the columns of one accumulator row
+// sum over the 16 lanes that share (lane >> 4): the columns of one accumulator row.  On the DPP path (VALU speed);
+// __shfl_xor would be a ds_bpermute, an LDS round trip per step
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float row_sum16(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    v += dpp_f<0xB1>(v);       // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_f<0x4E>(v);       // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_f<0x141>(v);      // row_half_mirror: the other quad of the half row
+    v += dpp_f<0x140>(v);      // row_mirror: the other half row
     return v;
 }
 
