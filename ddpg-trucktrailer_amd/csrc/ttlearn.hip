@@ -626,21 +626,29 @@ struct AdamFused {
     int on;
 };
 
-__device__ __forceinline__ void adam_apply(const AdamFused &A, const int t, const size_t i, const float grad,
-                                           const float bc1, const float sqrt_bc2) {
-    float p = A.p[t][i];
-    const float g = fmaf(A.weight_decay, p, grad);
-    const float m = fmaf(A.beta1, A.m[t][i], (1.f - A.beta1) * g);
-    const float v = fmaf(A.beta2, A.v[t][i], (1.f - A.beta2) * g * g);
+struct AdamElem { float p, m, v, tg; };
+
+__device__ __forceinline__ AdamElem adam_load(const AdamFused &A, const int t, const size_t i) {
+    return AdamElem{A.p[t][i], A.m[t][i], A.v[t][i], A.tgt[t] ? A.tgt[t][i] : 0.f};
+}
+
+// k_adam_soft's arithmetic on one element already loaded
+__device__ __forceinline__ void adam_finish(const AdamFused &A, const int t, const size_t i, const float grad, AdamElem e,
+                                            const float bc1, const float sqrt_bc2) {
+    const float g = fmaf(A.weight_decay, e.p, grad);
+    const float m = fmaf(A.beta1, e.m, (1.f - A.beta1) * g);
+    const float v = fmaf(A.beta2, e.v, (1.f - A.beta2) * g * g);
     A.m[t][i] = m;
     A.v[t][i] = v;
     const float denom = sqrtf(v) / sqrt_bc2 + A.eps;
-    p -= (A.lr / bc1) * (m / denom);
+    const float p = e.p - (A.lr / bc1) * (m / denom);
     A.p[t][i] = p;
-    if (A.tgt[t]) {
-        const float tg = A.tgt[t][i];
-        A.tgt[t][i] = fmaf(A.tau, p - tg, tg);
-    }
+    if (A.tgt[t]) A.tgt[t][i] = fmaf(A.tau, p - e.tg, e.tg);
+}
+
+__device__ __forceinline__ void adam_apply(const AdamFused &A, const int t, const size_t i, const float grad,
+                                           const float bc1, const float sqrt_bc2) {
+    adam_finish(A, t, i, grad, adam_load(A, t, i), bc1, sqrt_bc2);
 }
 
 struct Grads {
@@ -707,13 +715,20 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
         const f32x4 p3 = *reinterpret_cast<const f32x4 *>(&part[3][wave][lane * 4]);
         const int col = grp * 64 + 4 * l15 + wave;                       // tile t holds columns c0 + t
         if (col < H1 && grp * 64 + 4 * l15 < H1) {
+            // the four elements' optimizer state first: the updates below store through pointers that may alias a later load
+            AdamElem el[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jr = jt * 16 + l4 * 4 + r;
+                if (A.on && jr < H2) el[r] = adam_load(A, 4, (size_t)jr * H1 + col);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int jr = jt * 16 + l4 * 4 + r;
                 if (jr < H2) {
                     const float g = ((p0[r] + p1[r]) + p2[r]) + p3[r];
                     G.w2[(size_t)jr * H1 + col] = g;
-                    if (A.on) adam_apply(A, 4, (size_t)jr * H1 + col, g, bc1, sqrt_bc2);
+                    if (A.on) adam_finish(A, 4, (size_t)jr * H1 + col, g, el[r], bc1, sqrt_bc2);
                 }
             }
         }
@@ -745,12 +760,16 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
         if (wave < 2) {
             const int col = wave * 16 + l15;
             if (col < IN) {
+                AdamElem el[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (A.on) el[r] = adam_load(A, 0, (size_t)(jt * 16 + l4 * 4 + r) * IN + col);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float g = ((part[0][wave][lane * 4 + r] + part[1][wave][lane * 4 + r]) + part[2][wave][lane * 4 + r]) +
                                     part[3][wave][lane * 4 + r];
                     G.w1[(size_t)(jt * 16 + l4 * 4 + r) * IN + col] = g;
-                    if (A.on) adam_apply(A, 0, (size_t)(jt * 16 + l4 * 4 + r) * IN + col, g, bc1, sqrt_bc2);
+                    if (A.on) adam_finish(A, 0, (size_t)(jt * 16 + l4 * 4 + r) * IN + col, g, el[r], bc1, sqrt_bc2);
                 }
             }
         }
