@@ -507,33 +507,9 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
     for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int c0 = wave * 64 + 4 * l15;
     const bool gok = wave < NG && c0 < H1;
-    if (wave < NG) {
-        const float *arow = dx2_s + l15 * DS + 4 * l4;
-        const float *wcol = W.w2 + (gok ? c0 : 0);
-#pragma unroll 3
-        for (int c = 0; c < H2K / 16; ++c) {
-            const float4 av4 = *reinterpret_cast<const float4 *>(arow + 16 * c);
-            float4 bv[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int j = 16 * c + 4 * l4 + ks;          // row of fc2 = the k of this product
-                bv[ks] = (gok && j < H2) ? *reinterpret_cast<const float4 *>(wcol + (size_t)j * H1)
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            const float a[4] = {av4.x, av4.y, av4.z, av4.w};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv[ks].x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv[ks].y, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv[ks].z, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv[ks].w, acc[3], 0, 0, 0);
-            }
-        }
-    }
-    STAMP(10);
-    // ---- phase C: ReLU and LayerNorm1 backward; accumulator [t][r] is row l4*4+r, column wave*64 + 4*l15 + t
-    float xh1[4][4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    float4 hv[4], xv[4];                                   // loads of all four rows first (see phase A)
+    // what phase C needs from memory is requested now, so that it arrives behind phase B's MFMAs (and, as in phase A,
+    // before any store of phase C)
+    float4 hv[4], xv[4];
     const float4 gm = gok ? *reinterpret_cast<const float4 *>(W.g1 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
     float rs1[4];
 #pragma unroll
@@ -544,6 +520,53 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
         xv[r] = ok ? *reinterpret_cast<const float4 *>(sv.xh1 + (size_t)row * H1 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
         rs1[r] = ok ? sv.rstd1[row] : 0.f;
     }
+    if (wave < NG) {
+        const float *arow = dx2_s + l15 * DS + 4 * l4;
+        const float *wcol = W.w2 + (gok ? c0 : 0);
+        // software pipeline as in the forward's layer 2: the fc2 rows of the NEXT group of 3 k16 steps are requested before
+        // the 48 MFMAs of the current group issue (19 steps = 6 groups of 3 + 1)
+        constexpr int GU = 3, NSTEP = H2K / 16, NGRP = (NSTEP + GU - 1) / GU;
+        float4 bcur[GU][4], bnxt[GU][4];
+        auto load_group = [&](const int g, float4 (&dst)[GU][4]) {
+#pragma unroll
+            for (int u = 0; u < GU; ++u)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int c = g * GU + u, j = 16 * c + 4 * l4 + ks;          // row of fc2 = the k of this product
+                    dst[u][ks] = (gok && c < NSTEP && j < H2) ? *reinterpret_cast<const float4 *>(wcol + (size_t)j * H1)
+                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+        };
+        load_group(0, bcur);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+            if (g + 1 < NGRP) load_group(g + 1, bnxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int c = g * GU + u;
+                if (c < NSTEP) {
+                    const float4 av4 = *reinterpret_cast<const float4 *>(arow + 16 * c);
+                    const float a[4] = {av4.x, av4.y, av4.z, av4.w};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bcur[u][ks].x, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bcur[u][ks].y, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bcur[u][ks].z, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bcur[u][ks].w, acc[3], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < GU; ++u)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) bcur[u][ks] = bnxt[u][ks];
+        }
+    }
+    STAMP(10);
+    // ---- phase C: ReLU and LayerNorm1 backward; accumulator [t][r] is row l4*4+r, column wave*64 + 4*l15 + t
+    float xh1[4][4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = row0 + l4 * 4 + r;
