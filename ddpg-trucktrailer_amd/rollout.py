@@ -11,6 +11,7 @@ Everything stays on the device.  run(k) replays hipGraphs of `graph_steps` WHOLE
 learn(): about ten launches per step, back to back with no host in between); step() is the same vector step launched
 eagerly, with learn() alone captured (sampling included).  Both give the same bits."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -61,6 +62,11 @@ class DDPGRollout:
                 self.learner.enable_data_parallel()
         self.use_graph = use_graph and self.device.type == "cuda"
         self.dp = world_size > 1
+        if os.environ.get("TT_FORCE_DP") == "1" and self.learner is not None and not self.dp:
+            # measurement aid: the data-parallel launch structure (three graph segments, separate Adam launches) on ONE
+            # rank with no-op collectives -- what a rank's step costs before any time on the wire
+            self.dp = True
+            self.learner.grad_sync_critic = self.learner.grad_sync_actor = lambda: None
         self.graph = None
         self.vector_steps = 0
         # whole-step graphs: the ring slots a step touches depend on k mod slots only, so a graph of G steps captured at
