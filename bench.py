@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the MI355X truck-trailer hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  Started by `python -m torch.distributed.run ... bench.py --gpus N` the ranks read
+RANK / LOCAL_RANK / WORLD_SIZE from the environment; started as plain `python bench.py --gpus N` the parent -- before it
+touches any GPU -- starts those N ranks itself (torch.distributed.run as a child process), forwards their output and
+exits with their code, and refuses (exit 2, no JSON line) when fewer than N GPUs are visible: `n_gpus` in the line is
+always the number of ranks that ran.
 
 A "step" is one vector step over all envs of the rank.  Workloads:
   ddpg  (default, BASELINE.json config 3): actor forward + OU noise for N envs -> env step kernel
-        -> transitions into the device replay ring -> one DDPG learn() (batch 256) per vector step;
+        -> transitions into the device replay ring -> DDPG learn() (batch 256) per vector step;
   env   (config 2): random policy (Philox) -> env step kernel, auto-reset.
-Inputs are synthetic (reference reset distribution, random-init 400x300 networks) and resident in
-HBM before the timed region.  One JSON line on rank 0; see DESIGN.md "Measurement" for the fields."""
+--variant simv1 runs either on the simv1 constants / termination mask / stateless reward / pose pool (config 5;
+parity unpinned).  Inputs are synthetic (reference reset distribution, random-init 400x300 networks) and
+resident in HBM before the timed region.  One JSON line on rank 0; see DESIGN.md "Measurement" for the fields."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,6 +30,7 @@ if ROOT not in sys.path:
 
 B_ALG = 313            # algorithmic bytes per env-step
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def parse():
@@ -30,10 +40,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n-envs", type=int, default=65536, help="envs PER GPU (weak scaling)")
     ap.add_argument("--workload", choices=("ddpg", "env"), default="ddpg")
+    ap.add_argument("--variant", choices=("simv2", "simv1"), default="simv2")
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--updates-per-step", type=int, default=1, help="learn() calls per vector step")
     ap.add_argument("--replay-slots", type=int, default=64, help="ring length in vector steps (capacity = slots*N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--repeats", type=int, default=5, help="extra hipEvent-timed repeats of the K steps after the timed region")
     ap.add_argument("--no-graph", action="store_true", help="launch everything eagerly (no hipGraphs)")
     ap.add_argument("--step-graph", type=int, default=4, help="ddpg workload: whole vector steps per captured hipGraph "
                     "(0: only learn() is captured)")
@@ -42,15 +55,99 @@ def parse():
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------ N > 1 launcher
+def spawn_ranks(args):
+    """Parent of a plain `python bench.py --gpus N`: starts the N ranks and relays them.  Touches no GPU itself
+    (torch.cuda.device_count() does not initialise one on this image)."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible; refusing to print a line for fewer ranks",
+              file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
 def pmc_traffic(n):
-    """HBM bytes per k_step launch from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc
+    """HBM bytes per k_step launch from the committed PMC passes (profiles/r0X_pmc_traffic.json: rocprofv3 --pmc
     FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    bench.py cannot collect counters itself; null when the summary is absent."""
+    bench.py cannot collect counters itself; (None, None) when no summary is present."""
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return float(json.load(f)["traffic_B_per_env_step"]) * n, "profiles/" + name
+        except Exception:
+            continue
+    return None, None
+
+
+def _twin_worker(seconds, seed, q):
+    """One process of the all-cores baseline: the structure-faithful twin, random policy, reset on done."""
+    import numpy as np
+    from oracle.simv2_twin import Simv2Twin
+    env = Simv2Twin()
+    rng = np.random.RandomState(seed)
+    env.reset(seed=seed)
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(200):
+            if env.step(np.array([rng.uniform(-1, 1) * np.pi / 4], np.float32))[2]:
+                env.reset()
+        n += 200
+    q.put((n, time.perf_counter() - t0))
+
+
+def host_cpu():
+    """(model name, physical cores this process may run on, logical CPUs it may run on)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    model, cores, cur = "unknown", set(), {}
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return float(json.load(f)["traffic_B_per_env_step"]) * n
-    except Exception:
-        return None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if ":" not in line:
+                    if cur.get("processor") in allowed:
+                        cores.add((cur.get("physical id", 0), cur.get("core id", cur.get("processor"))))
+                    cur = {}
+                    continue
+                k, v = (x.strip() for x in line.split(":", 1))
+                if k == "model name":
+                    model = v
+                elif k in ("processor", "physical id", "core id"):
+                    cur[k] = int(v)
+        if cur.get("processor") in allowed:
+            cores.add((cur.get("physical id", 0), cur.get("core id", cur.get("processor"))))
+    except OSError:
+        pass
+    return model, (len(cores) or len(allowed)), len(allowed)
+
+
+def cpu_twin_all_cores(seconds, procs):
+    """SURVEY 8d CPU baseline (2): one twin process per physical core (multiprocessing, spawn: fresh interpreters)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_twin_worker, args=(seconds, 1000 + i, q)) for i in range(procs)]
+    t0 = time.perf_counter()
+    for p in ps:
+        p.start()
+    res = [q.get() for _ in ps]
+    for p in ps:
+        p.join()
+    wall = time.perf_counter() - t0
+    steps = sum(r[0] for r in res)
+    rate = sum(r[0] / r[1] for r in res)
+    return {"value": rate, "unit": "env-steps/s", "cores": procs,
+            "sample": f"{steps} steps of oracle/simv2_twin.py in {procs} processes (one per physical core), "
+                      f"{seconds:.0f} s each, {wall:.1f} s wall incl. start-up"}
 
 
 def cpu_full_loop(seconds=6.0, batch=256):
@@ -87,12 +184,13 @@ def cpu_full_loop(seconds=6.0, batch=256):
 
 
 def cpu_baseline(seconds):
-    """Oracle timed on the host cores (rank 0, N=1 only): the structure-faithful Python/scipy twin of the
-    reference's step loop on ONE core (the reference is single-threaded), random policy, reset on done.
-    The plain-C port on all cores is reported next to it as the optimised-CPU line."""
+    """Oracle timed on the host cores (rank 0, N=1 only, BEFORE this process touches the GPU): the structure-faithful
+    Python/scipy twin of the reference's step loop -- on ONE core (the reference is single-threaded; this is `value`)
+    and in one process per physical core; beside them the whole loop on torch-CPU and the plain-C port on all cores."""
     import numpy as np
     from oracle import c_oracle
     from oracle.simv2_twin import Simv2Twin
+    model, phys, logical = host_cpu()
     env = Simv2Twin()
     rng = np.random.RandomState(0)
     env.reset(seed=0)
@@ -107,30 +205,45 @@ def cpu_baseline(seconds):
                 env.reset()
         n += 500
     dt = time.perf_counter() - t0
-    cores = len(os.sched_getaffinity(0))
-    c_oracle.rollout_random(256, 50, seed=1, nthreads=cores)
+    c_oracle.rollout_random(256, 50, seed=1, nthreads=logical)
     t1 = time.perf_counter()
-    cn, _ = c_oracle.rollout_random(4096, 400, seed=2, nthreads=cores)
+    cn, _ = c_oracle.rollout_random(4096, 400, seed=2, nthreads=logical)
     cdt = time.perf_counter() - t1
-    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} steps of oracle/simv2_twin.py (numpy + scipy solve_ivp RK45 + reward object per step), "
-                      f"uniform-random steering, reset on done, {dt:.1f} s",
-            "full_loop": cpu_full_loop(),
-            "c_port": {"value": cn / cdt, "unit": "env-steps/s", "cores": cores,
-                       "sample": f"{cn} steps of oracle/tt_oracle.c (fixed DP5, OpenMP), {cdt:.2f} s"}}
+    out = {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port", "cpu_model": model,
+           "physical_cores": phys, "logical_cpus": logical,
+           "sample": f"{n} steps of oracle/simv2_twin.py (numpy + scipy solve_ivp RK45 + reward object per step), "
+                     f"uniform-random steering, reset on done, {dt:.1f} s"}
+    try:
+        out["all_cores"] = cpu_twin_all_cores(max(4.0, seconds * 0.6), phys)
+    except Exception as exc:      # a box that refuses child processes still gets the one-core line
+        out["all_cores"] = {"error": repr(exc)}
+    out["full_loop"] = cpu_full_loop()
+    out["c_port"] = {"value": cn / cdt, "unit": "env-steps/s", "cores": logical,
+                     "sample": f"{cn} steps of oracle/tt_oracle.c (fixed DP5, OpenMP), {cdt:.2f} s"}
+    return out
 
 
+# ------------------------------------------------------------------------------------------------ the bench proper
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        args.gpus = world                      # the line reports the ranks that actually run
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_seconds)   # before any GPU call: its worker processes start from a GPU-free parent
+
+    import torch
+    import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path is a HIP kernel)"
+    if world > 1 and os.environ.get("TT_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < world:
+        print(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s)", file=sys.stderr, flush=True)
+        sys.exit(2)
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -147,8 +260,14 @@ def main():
     from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
 
     n = args.n_envs
-    env = TruckTrailerVecEnv(n, device=dev)
+    variant = 1 if args.variant == "simv1" else 0
+    env = TruckTrailerVecEnv(n, device=dev, variant=variant)
+    if variant == 1:
+        from ddpg_trucktrailer_amd import simv1_reset
+        env.set_reset_pool(simv1_reset.generate_pose_pool(1024, seed=27 + rank))     # simv1.py:255-282 (host logic)
     env.reset(seed=27 + rank)
+    vname = ("simv1 (L1 5.74, L2 10.192, 300-step cap, mask jackknife|out-of-map|max-steps|goal, stateless reward, "
+             "Dubins-feasible pose pool; PARITY UNPINNED)") if variant else "simv2"
 
     graph_k = 1
     ddpg_loop = None
@@ -170,61 +289,74 @@ def main():
                 for _ in range(graph_k):
                     env.step_random(123 + rank, auto_reset=True)
 
-        def one_step(timed):
-            if graph is not None:
-                graph.replay()
-            else:
-                env.step_random(123 + rank, auto_reset=True)
-        workload = (f"simv2 N={n}/GPU, random policy U(-1,1)*pi/4 drawn in-kernel, auto-reset "
-                    f"(BASELINE config 2 at bench size), hipGraph of {graph_k} steps")
+        def run(k_steps):
+            for _ in range(k_steps // graph_k):
+                if graph is not None:
+                    graph.replay()
+                else:
+                    env.step_random(123 + rank, auto_reset=True)
+        workload = (f"{vname} N={n}/GPU, random policy U(-1,1)*pi/4 drawn in-kernel, auto-reset "
+                    f"(BASELINE config {5 if variant else 2} at bench size), hipGraph of {graph_k} steps")
         extra = {"graph_steps": graph_k}
     else:
         from ddpg_trucktrailer_amd.rollout import DDPGRollout
         loop = DDPGRollout(env, batch_size=args.batch, replay_slots=args.replay_slots, seed=27 + rank,
                            world_size=world, use_graph=not args.no_graph, fused_learn=not args.torch_learn,
-                           graph_steps=args.step_graph)
-
+                           graph_steps=args.step_graph, updates_per_step=args.updates_per_step)
         loop.prepare()       # one-off work (4 untimed vector steps + graph capture) before warm-up and the timed region
-
-        def one_step(timed):
-            loop.step()
         ddpg_loop = loop
-        workload = (f"simv2 N={n}/GPU + full DDPG learn() per vector step (actor/critic 400x300, batch {args.batch}, "
-                    f"OU noise, replay ring {args.replay_slots}xN) (BASELINE config 3)")
-        extra = {"batch": args.batch, "replay_capacity": args.replay_slots * n,
-                 "launch": (f"hipGraphs of {loop.graph_steps} whole vector steps" if loop.graph_steps else
-                            ("eager, learn() as a hipGraph" if loop.use_graph else "eager"))}
+        run = loop.run       # every step a hipGraph replay (G-step graphs where aligned, single-step graphs elsewhere)
+        workload = (f"{vname} N={n}/GPU + full DDPG learn() x{args.updates_per_step} per vector step (actor/critic 400x300, "
+                    f"batch {args.batch}, OU noise, replay ring {args.replay_slots}xN) (BASELINE config {5 if variant else 3})")
+        if loop.graph_steps:
+            launch = (f"every vector step a hipGraph replay: graphs of {loop.graph_steps} whole steps at aligned ring positions, "
+                      f"single-step graphs elsewhere" if not loop.dp else
+                      "three hipGraph segments per step with the two RCCL gradient all-reduces between them")
+        else:
+            launch = "eager, learn() as a hipGraph" if loop.use_graph else "eager"
+        extra = {"batch": args.batch, "updates_per_step": args.updates_per_step,
+                 "replay_capacity": args.replay_slots * n, "launch": launch}
 
-    def run(k_steps, timed):
-        if ddpg_loop is not None:
-            ddpg_loop.run(k_steps)       # hipGraphs of whole vector steps (policy + env step + learn), eager remainder
-            return
-        for _ in range(k_steps // graph_k):
-            one_step(timed)
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
 
-    run(args.warmup, False)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    run(args.warmup)
+    sync_all()
     captured = graph_k > 1 or (ddpg_loop is not None and ddpg_loop.graph_steps > 0)
     if not captured:
         env.profile(args.steps)      # per-dispatch HIP events on the step kernel, inside the timed region
+    stream = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    run(args.steps, True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    e0.record(stream)
+    run(args.steps)
+    e1.record(stream)
+    sync_all()
     elapsed = time.perf_counter() - t0
+    event_ms = e0.elapsed_time(e1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # hipEvent-timed repeats of the same K steps, median and spread (the line's value stays the contract's
+    # wall-clock region above)
+    reps = []
+    for _ in range(max(0, args.repeats)):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        run(args.steps)
+        b.record(stream)
+        sync_all()
+        reps.append(a.elapsed_time(b) / args.steps)
     if captured:
         # a captured launch cannot carry its own events: time the same kernel in the same loop on the same state right
         # after, eagerly, with the per-dispatch events (the timed region above is untouched by this)
-        env.profile(min(args.steps, 2000))
-        for _ in range(min(args.steps, 2000)):
+        m = min(args.steps, 2000)
+        env.profile(m)
+        for _ in range(m):
             if ddpg_loop is not None:
                 ddpg_loop.step()
             else:
@@ -235,42 +367,50 @@ def main():
     total_env_steps = n * world * args.steps
     value = total_env_steps / elapsed
     achieved = (B_ALG * n) / (kern_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(n)
     out = {
         "metric": "env-steps/s", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": dict({"workload": workload, "n_envs_per_gpu": n, "n_envs_total": n * world}, **extra),
+        "timing": {"wall_ms_per_step": elapsed / args.steps * 1e3, "event_ms_per_step": event_ms / args.steps,
+                   "repeats": len(reps), "repeat_event_ms_per_step": reps,
+                   "median_ms_per_step": (sorted(reps)[len(reps) // 2] if reps else None),
+                   "spread_ms_per_step": ((max(reps) - min(reps)) if reps else None)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n), "kernel": "k_step",
-                     "kernel_ms": kern_ms, "alg_bytes_per_env_step": B_ALG,
-                     "kernel_env_steps_per_s": n / (kern_ms * 1e-3)},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "k_step", "kernel_ms": kern_ms, "alg_bytes_per_env_step": B_ALG,
+                     "kernel_env_steps_per_s": n / (kern_ms * 1e-3),
+                     "timed": ("per-dispatch HIP events on eager launches of the same loop right after the timed region"
+                               if captured else "per-dispatch HIP events inside the timed region")},
     }
     if ddpg_loop is not None and ddpg_loop.fused_act:
-        # the loop's largest kernel is the N-env policy forward (k_split_pack + k_mlp_split, csrc/ttnet_split.hip): MFMA-bound.
+        # the loop's largest kernel is the N-env policy forward (csrc/ttnet_split.hip): MFMA-bound.
         # Events on the launch stream around 20 back-to-back choose_action launches, right after the timed region.
         ring = ddpg_loop.ring
         t = ring.slot()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ddpg_loop.act(ring.obs[t], ring.act[t], None)
-        e0.record()
+        a0.record()
         for _ in range(20):
             ddpg_loop.act(ring.obs[t], ring.act[t], None)
-        e1.record()
+        a1.record()
         torch.cuda.synchronize()
-        act_ms = e0.elapsed_time(e1) / 20
-        waves = 4 * ((n + 127) // 128)
-        bf16_flop = waves * 1500 * 32768.0          # v_mfma_f32_32x32x16_bf16: 25 k16 steps x 10 tiles x 6 products per wave
+        act_ms = a0.elapsed_time(a1) / 20
+        from ddpg_trucktrailer_amd import fused
+        info = fused.policy_kernel_info(n)
+        useful = 2.0 * n * (23 * 400 + 400 * 300 + 300)
         out["roofline_mfma"] = {
-            "bound": "mfma", "kernel": "k_split_pack + k_mlp_split (choose_action for N envs)", "kernel_ms": act_ms,
-            "achieved": bf16_flop / (act_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-            "frac": bf16_flop / (act_ms * 1e-3) / 1e12 / 2500.0, "traffic": None,
-            "note": "bf16 MFMA FLOP executed (six bf16 products per f32 product block) over dense bf16 peak; layer 1 "
-                    "(f32 MFMA, 2 % of the FLOP) not counted",
-            "algorithmic_f32_tflops": 2.0 * n * (23 * 400 + 400 * 300 + 300) / (act_ms * 1e-3) / 1e12,
+            "bound": "mfma", "kernel": info["kernel"], "kernel_ms": act_ms,
+            "achieved": info["mfma_flop"] / (act_ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": info["mfma_flop"] / (act_ms * 1e-3) / 1e12 / 2500.0, "traffic": None,
+            "note": info["note"],
+            "algorithmic_f32_tflops": useful / (act_ms * 1e-3) / 1e12,
+            "algorithmic_frac_of_16bit_peak": useful / (act_ms * 1e-3) / 1e12 / 2500.0,
             "f32_mfma_peak_tflops": 157.3}
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -7,6 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TT_LIB_PATH") or os.path.join(HERE, "libttenv.so")  # override: kernel-variant A/B runs
 
 OBS_DIM = 23
+MAX_EPISODE_STEPS = 4095      # TT_MAX_EPISODE_STEPS
 TT_OK, TT_EINVAL, TT_ENOMEM, TT_EHIP, TT_ENODEV = 0, -1, -2, -3, -4
 F_JACKKNIFE, F_OUT_OF_MAP, F_MAX_STEPS, F_GOAL_REACHED, F_GOAL_PASSED, F_EXCESSIVE_BACK, F_SUCCESS = (1 << i for i in range(7))
 VIOLATIONS = ("none", "jackknife", "jackknife_warning", "major_boundary", "minor_boundary", "past_the_goal",
@@ -57,6 +58,11 @@ class TTDqdaInput(C.Structure):
     _fields_ = [("critic", C.POINTER(TTMlpWeights)), ("q_out", C.c_void_p), ("dq_da", C.c_void_p)]
 
 
+class TTSideBuffer(C.Structure):
+    _fields_ = [("obs", C.c_void_p), ("act", C.c_void_p), ("rew", C.c_void_p), ("obs2", C.c_void_p), ("done", C.c_void_p),
+                ("count", C.c_int32), ("reserved_", C.c_int32)]
+
+
 class TTMlpBwdWs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dpre", "dz", "dx2", "dy1", "dx1")]
 
@@ -95,7 +101,7 @@ _SIGNATURES = {
     "tt_actor_forward": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_actor_act": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P, _U64, _U64, _P, C.c_float, C.c_float, C.c_float,
                                _P, _P, _P, _P]),
-    "tt_ring_sample": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _U64, _P, _P, _P, _P, _P, _P, _P]),
+    "tt_ring_sample": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _U64, C.POINTER(TTSideBuffer), _P, _P, _P, _P, _P, _P, _P]),
     "tt_critic_forward": (C.c_int, [_I, _P, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_mlp_forward_save": (C.c_int, [_I, _I, _P, _P, C.POINTER(TTMlpWeights), _P, C.POINTER(TTMlpSaved), _P, _P]),
     "tt_mlp_forward_multi": (C.c_int, [_I, _I, C.POINTER(TTFwdJob), _P]),

@@ -58,6 +58,7 @@ class Agent():
                                            name='target_critic', **kw)
         self.update_network_parameters(tau=1)
         self._critic_params = list(self.critic.parameters())
+        self._actor_params = list(self.actor.parameters())
         self.grad_sync_actor = self.grad_sync_critic = None
         self.fused_targets = False
         self.fused_learner = None      # set by DDPGRollout when learn() runs on the hand-fused kernels
@@ -122,23 +123,23 @@ class Agent():
             target = (rewards + self.gamma * critic_value_).view(-1, 1)
         critic_value = self.critic.forward(states, actions)
 
-        self.critic.optimizer.zero_grad(set_to_none=True)
+        # Gradients through torch.autograd.grad, not .backward(): backward() delivers them through each parameter's
+        # AccumulateGrad node, which is pinned to the stream it was first used on -- a node kept alive from another stream
+        # (e.g. by a clone of the parameter that still carries its grad_fn) forks a hipGraph capture of this function and
+        # HIP's EndCapture then crashes the process.  grad() returns the same numbers without touching those nodes.
         critic_loss = F.mse_loss(target, critic_value)
-        critic_loss.backward()
+        for p, g in zip(self._critic_params, T.autograd.grad(critic_loss, self._critic_params)):
+            p.grad = g                                       # zero_grad(set_to_none=True) + backward()
         if self.grad_sync_critic is not None:
             self.grad_sync_critic()
         self.critic.optimizer.step()
 
         # The actor step differentiates -Q(s, mu(s)) through the ALREADY UPDATED critic.  The reference lets
         # that backward also deposit gradients in the critic's parameters and throws them away at the next
-        # zero_grad (DDPG_agent.py:95,100-104); not computing them changes nothing the optimizers see.
-        self.actor.optimizer.zero_grad(set_to_none=True)
-        for p in self._critic_params:
-            p.requires_grad_(False)
+        # zero_grad (DDPG_agent.py:95,100-104); asking for the actor's gradients only changes nothing the optimizers see.
         actor_loss = T.mean(-self.critic.forward(states, self.actor.forward(states)))
-        actor_loss.backward()
-        for p in self._critic_params:
-            p.requires_grad_(True)
+        for p, g in zip(self._actor_params, T.autograd.grad(actor_loss, self._actor_params)):
+            p.grad = g
         if self.grad_sync_actor is not None:
             self.grad_sync_actor()
         self.actor.optimizer.step()

@@ -9,30 +9,48 @@ import numpy as np
 import torch
 
 
+def _rng_state():
+    kind, keys, pos, has_gauss, gauss = np.random.get_state()
+    rng = {"torch": torch.get_rng_state(),
+           "numpy": {"kind": str(kind), "keys": torch.from_numpy(keys.astype(np.int64)), "pos": int(pos),
+                     "has_gauss": int(has_gauss), "gauss": float(gauss)}}
+    if torch.cuda.is_available():
+        rng["cuda"] = torch.cuda.get_rng_state()
+    return rng
+
+
+def _restore_rng(rng):
+    torch.set_rng_state(rng["torch"])
+    nps = rng.get("numpy")
+    if isinstance(nps, dict):       # the full legacy-MT state: keys, position and the cached Gaussian (noise.py / replay draws)
+        np.random.set_state((nps["kind"], nps["keys"].numpy().astype(np.uint32), nps["pos"], nps["has_gauss"], nps["gauss"]))
+    if "cuda" in rng and torch.cuda.is_available():
+        torch.cuda.set_rng_state(rng["cuda"])
+
+
 def save_training_checkpoint(path, agent, env=None, ring=None, noise=None, training_state=None, with_replay=True):
     if getattr(agent, "fused_learner", None) is not None:
         agent.fused_learner.export_to_optimizers()          # Adam moments live in the fused learner's flat buffers
-    ck = {"format": 1,
+    ck = {"format": 2,
           "nets": {n: getattr(agent, n).state_dict() for n in ("actor", "critic", "target_actor", "target_critic")},
           "optim": {"actor": agent.actor.optimizer.state_dict(), "critic": agent.critic.optimizer.state_dict()},
           "hyper": dict(alpha=agent.alpha, beta=agent.beta, tau=agent.tau, gamma=agent.gamma, batch_size=agent.batch_size),
           "training_state": training_state or {},
-          "rng": {"torch": torch.get_rng_state(), "numpy": np.random.get_state()[1].tolist()}}
-    if torch.cuda.is_available():
-        ck["rng"]["cuda"] = torch.cuda.get_rng_state()
+          "rng": _rng_state()}
     if env is not None:
         ck["env"] = env.state_dict()
     if noise is not None:
         ck["ou"] = noise.x.detach().cpu()
     if ring is not None:
-        ck["ring"] = {"k": ring.k, "slots": ring.slots, "n": ring.n}
-        if with_replay:
-            ck["ring"].update(obs=ring.obs.cpu(), act=ring.act.cpu(), rew=ring.rew.cpu(), done=ring.done.cpu())
+        ck["ring"] = ring.state_dict(with_replay=with_replay)
     torch.save(ck, path)
     return path
 
 
 def load_training_checkpoint(path, agent, env=None, ring=None, noise=None):
+    """Restores everything save_training_checkpoint wrote.  Load BEFORE DDPGRollout.prepare()/run() capture their
+    graphs, or through DDPGRollout.load_state_dict (which re-captures): a captured step launch bakes the env's reset
+    seed and modes by value."""
     ck = torch.load(path, map_location="cpu", weights_only=True)
     for n, sd in ck["nets"].items():
         getattr(agent, n).load_state_dict(sd)
@@ -45,13 +63,21 @@ def load_training_checkpoint(path, agent, env=None, ring=None, noise=None):
     if noise is not None and "ou" in ck:
         noise.x.copy_(ck["ou"].to(noise.x.device))
     if ring is not None and "ring" in ck:
-        r = ck["ring"]
-        assert (r["slots"], r["n"]) == (ring.slots, ring.n), "replay ring geometry differs"
-        if "obs" in r:
-            ring.obs.copy_(r["obs"]); ring.act.copy_(r["act"]); ring.rew.copy_(r["rew"]); ring.done.copy_(r["done"])
-            ring.k = int(r["k"])
-            ring.k_dev.fill_(ring.k)
-    torch.set_rng_state(ck["rng"]["torch"])
+        ring.load_state_dict(ck["ring"])       # counters always; contents when they were saved
+    _restore_rng(ck["rng"])
+    return ck.get("training_state", {})
+
+
+def save_loop_checkpoint(path, loop, training_state=None):
+    """The whole N-env loop (DDPGRollout.state_dict: networks, Adam state, env batch, replay ring + side buffer, OU state,
+    counters) in one file; a loop restored from it continues bit for bit (tests/test_gpu_rollout.py)."""
+    torch.save({"format": 2, "loop": loop.state_dict(), "training_state": training_state or {}}, path)
+    return path
+
+
+def load_loop_checkpoint(path, loop):
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    loop.load_state_dict(ck["loop"])
     return ck.get("training_state", {})
 
 

@@ -508,7 +508,12 @@ __device__ __forceinline__ void step_env(const KParams &P, Env &e, float action,
     observe(P, e.g, e.x1, e.y1, e.x2, e.y2, s1, c1, s2, c2, sd, cd, dx, dy, cur, inv_cur, of);
 
     // ---- reward (reward_functionv1.py:442-506)
-    const int rmax = (int)(init * P.inv_step_length) + P.extra_steps;
+    // int(initial_distance / 0.40096) + 75 (:38): the quotient by one multiplication, and by the real division (what
+    // numpy does) only where the two could truncate differently -- next to an integer (wave-uniform, almost never)
+    const double rq = init * P.inv_step_length;
+    int rmax = (int)rq;
+    if (__any(fabs(rq - rint(rq)) <= 1e-11 * rq)) rmax = (int)(init / P.step_length);
+    rmax += P.extra_steps;
     const float steer_now = tt_atan2_readback(delta, sd, cd, of[10], of[11]);  // np.arctan2(obs[10], obs[11]) (:37)
     if (first) {
         e.cum = 0.0;
@@ -1004,13 +1009,6 @@ int tt_env_create(int n_envs, int device, const tt_params *params, tt_env **out)
     if (!out) return fail(nullptr, TT_EINVAL, "tt_env_create: out is NULL");
     *out = nullptr;
     if (n_envs <= 0) return fail(nullptr, TT_EINVAL, "tt_env_create: n_envs must be positive (got %d)", n_envs);
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
-        return fail(nullptr, TT_ENODEV, "tt_env_create: no HIP device visible");
-    if (device < 0) {
-        if (hipGetDevice(&device) != hipSuccess) device = 0;
-    }
-    if (device >= count) return fail(nullptr, TT_ENODEV, "tt_env_create: device %d of %d", device, count);
     tt_params p;
     if (params) p = *params;
     else tt_params_default(0, &p);
@@ -1022,6 +1020,21 @@ int tt_env_create(int n_envs, int device, const tt_params *params, tt_env **out)
     if (!(turn <= 0.25) || !(std::fabs(p.max_steer) < 1.5))
         return fail(nullptr, TT_EINVAL, "tt_env_create: dt*|v|/L = %.3f rad per step exceeds the 0.25 rad the integrator's "
                                         "small-angle stage rotations are sized for", turn);
+    {   // episode lengths must fit the 12-bit packed counters (steps | max_episode_steps)
+        const double w = p.map_max_x - p.map_min_x, hgt = p.map_max_y - p.map_min_y;
+        const double longest = p.fixed_max_steps > 0 ? (double)p.fixed_max_steps
+                                                     : std::sqrt(w * w + hgt * hgt) * 1.5 / p.step_length + p.extra_steps;
+        if (p.fixed_max_steps < 0 || p.extra_steps < 0 || !(longest <= (double)TT_MAX_EPISODE_STEPS))
+            return fail(nullptr, TT_EINVAL, "tt_env_create: episodes of up to %.0f steps exceed the %d the packed counters hold",
+                        longest, TT_MAX_EPISODE_STEPS);
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(nullptr, TT_ENODEV, "tt_env_create: no HIP device visible");
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= count) return fail(nullptr, TT_ENODEV, "tt_env_create: device %d of %d", device, count);
     tt_env *e = new (std::nothrow) tt_env;
     if (!e) return fail(nullptr, TT_ENOMEM, "tt_env_create: host allocation failed");
     e->n = n_envs;
@@ -1133,6 +1146,15 @@ int tt_env_set_max_steps(tt_env *env, const int32_t *idx, int k, const int32_t *
         return fail(env, TT_EINVAL, "tt_env_set_max_steps: k=%d outside [0,%d] or max_steps NULL", k, env->n);
     if (k == 0) return TT_OK;
     TT_HIP(env, hipSetDevice(env->device));
+    {   // the packed counters hold 12 bits: refuse what they cannot represent instead of clamping (not a hot call)
+        std::vector<int32_t> host((size_t)k);
+        TT_HIP(env, hipMemcpyAsync(host.data(), max_steps, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost, stream));
+        TT_HIP(env, hipStreamSynchronize(stream));
+        for (int j = 0; j < k; ++j)
+            if (host[(size_t)j] < 0 || host[(size_t)j] > TT_MAX_EPISODE_STEPS)
+                return fail(env, TT_EINVAL, "tt_env_set_max_steps: max_steps[%d] = %d outside [0, %d]", j, host[(size_t)j],
+                            TT_MAX_EPISODE_STEPS);
+    }
     hipLaunchKernelGGL(k_set_max_steps, dim3(grid_for(k)), dim3(BLOCK), 0, stream, env->n, env->b, idx, k, max_steps);
     TT_HIP(env, hipGetLastError());
     return TT_OK;

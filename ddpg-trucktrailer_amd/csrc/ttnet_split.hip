@@ -330,12 +330,14 @@ int split_pack(const tt_mlp_weights *w, void *ws, hipStream_t stream) {
 template <bool CRITIC>
 static int launch_split(int n, const float *obs, const float *action, const tt_mlp_weights *w, float *out,
                         const ActArgs &act, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
+    static bool attr[64] = {};      // per device: a function attribute set on one device says nothing about another
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TT_EHIP;
+    if (!attr[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_split<CRITIC>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return TT_EHIP;
-        attr = true;
+        attr[dev] = true;
     }
     hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3((n + ROWS - 1) / ROWS), dim3(256), LDS_BYTES, stream, n, obs, action,
                        to_weights(w), reinterpret_cast<const uint4 *>(w->split_ws), out, act);

@@ -1,9 +1,12 @@
-"""Expert-transition ingestion (SURVEY §8f-4): trainv2.py:457-466 re-inserts stored transitions
+"""Expert-transition ingestion (SURVEY 8f-4): trainv2.py:457-466 re-inserts stored transitions
 `(obs, action, reward, obs_next, done)` one `agent.remember` call at a time; exp_gen.py:77-110 produces them with
-the action already divided by radians(45).  Here they are loaded in bulk into the device replay memory (`ReplayBuffer`, the per-transition ring the
-reference-style `Agent.learn()` samples from)."""
+the action already divided by radians(45).  Here they are loaded in bulk into the device replay memory:
+
+  * `load_into_replay(buffer, ...)`  -- the per-transition `ReplayBuffer` the reference-style `Agent.learn()` samples;
+  * `load_into_ring(ring, ...)`      -- the side buffer of the `TrajectoryRing` the N-env loop samples: expert tuples are
+    not steps of any env's trajectory, so they sit next to the time-major ring and `tt_ring_sample` draws uniformly over
+    ring transitions and side transitions together (the reference draws uniformly over one buffer that holds both)."""
 import numpy as np
-import torch
 
 
 def transitions_to_arrays(stored_transitions):
@@ -22,3 +25,10 @@ def load_into_replay(buffer, stored_transitions):
     obs, act, rew, obs2, done = transitions_to_arrays(stored_transitions)
     buffer.store_batch(obs, act, rew, obs2, done)
     return len(rew)
+
+
+def load_into_ring(ring, stored_transitions, capacity=None):
+    """The same transitions into the N-env loop's replay (TrajectoryRing.load_side); returns the number loaded.
+    Loops holding captured hipGraphs of the sampling launch re-capture afterwards (ring.side_epoch moves)."""
+    obs, act, rew, obs2, done = transitions_to_arrays(stored_transitions)
+    return ring.load_side(obs, act[:, 0], rew, obs2, done, capacity=capacity)

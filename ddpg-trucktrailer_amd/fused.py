@@ -87,3 +87,13 @@ def actor_act(net, obs, ou_state, act_raw, act_scaled, seed, step=0, step_dev=No
                                   float(sigma * math.sqrt(dt)), float(high), _ptr(mu_out), _ptr(act_raw),
                                   _ptr(act_scaled), _stream(obs)))
     return act_scaled
+
+
+def policy_kernel_info(n):
+    """What the N-env policy forward executes on the matrix cores, for bench.py's roofline_mfma object."""
+    waves = 4 * ((n + 127) // 128)
+    return {"kernel": "k_split_pack + k_mlp_split (choose_action for N envs)",
+            # v_mfma_f32_32x32x16_bf16: 25 k16 steps x 10 tiles x 6 products per wave, 32768 FLOP each
+            "mfma_flop": waves * 1500 * 32768.0,
+            "note": "bf16 MFMA FLOP executed (six bf16 products per f32 product block) over the dense bf16 peak; layer 1 "
+                    "(f32 MFMA, 2 % of the FLOP) not counted; algorithmic_* = the network's useful f32 FLOP"}

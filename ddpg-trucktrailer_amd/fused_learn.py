@@ -193,6 +193,19 @@ class FusedLearner:
             self.grad_sync_actor()
             self.phase_c()
 
+    # ---- checkpoint ---------------------------------------------------------------------------------------------
+    def state_dict(self):
+        """Adam moments of both networks (flat, tt_mlp_weights order) and the learn-step count."""
+        return {"step": int(self.step_dev.item()),
+                "actor": {"m": self.actor.m.cpu(), "v": self.actor.v.cpu()},
+                "critic": {"m": self.critic.m.cpu(), "v": self.critic.v.cpu()}}
+
+    def load_state_dict(self, sd):
+        for name in ("actor", "critic"):
+            st = getattr(self, name)
+            st.m.copy_(sd[name]["m"]); st.v.copy_(sd[name]["v"])
+        self.step_dev.fill_(int(sd["step"]))
+
     # ---- checkpoint interoperability with the torch optimizers ------------------------------------------
     def export_to_optimizers(self):
         step = self.step_dev.to(torch.float32).clone()

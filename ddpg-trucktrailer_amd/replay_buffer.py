@@ -65,6 +65,12 @@ class TrajectoryRing:
         self.k = 0                                                          # vector steps completed (host)
         self.k_dev = torch.zeros((), dtype=torch.int64, device=device)      # same, on the device (graph-safe)
         self._env_counts = False                                            # True: the env's step kernel advances k_dev
+        # stand-alone transitions (expert tuples, trainv2.py:457-466) that take part in every uniform draw.  Fixed
+        # capacity and fixed addresses (a captured sampling launch keeps pointing at them); only `count` moves, and a
+        # launch bakes it by value: holders of captured graphs re-capture when side_epoch moves
+        self.side = None
+        self.side_count = 0
+        self.side_epoch = 0
 
     def attach(self, env):
         """Let the env's step kernel advance k_dev (tt_env_set_step_counter): one launch less per vector step.  From
@@ -87,6 +93,66 @@ class TrajectoryRing:
         if not self._env_counts:
             self.k_dev += 1
 
+    # ---- expert / stand-alone transitions ---------------------------------------------------------------
+    def load_side(self, obs, act, rew, obs2, done, capacity=None):
+        """Append k stand-alone transitions (obs [k,23], act [k] or [k,1], rew [k], obs2 [k,23], done [k]) to the side
+        buffer the sampler mixes into its uniform draw: the bulk form of the reference's `agent.remember` loop over
+        stored expert transitions (trainv2.py:457-466).  The first call fixes the capacity (default: k)."""
+        f = dict(dtype=torch.float32, device=self.device)
+        obs = torch.as_tensor(obs, **f).reshape(-1, self.obs.shape[2])
+        k = obs.shape[0]
+        if self.side is None:
+            cap = int(capacity) if capacity is not None else k
+            d = self.obs.shape[2]
+            self.side = dict(obs=torch.zeros((cap, d), **f), act=torch.zeros(cap, **f), rew=torch.zeros(cap, **f),
+                             obs2=torch.zeros((cap, d), **f), done=torch.zeros(cap, dtype=torch.uint8, device=self.device))
+        cap = self.side["act"].shape[0]
+        if self.side_count + k > cap:
+            raise ValueError(f"side buffer holds {cap} transitions, {self.side_count} used, {k} more do not fit")
+        a, b = self.side_count, self.side_count + k
+        self.side["obs"][a:b] = obs
+        self.side["act"][a:b] = torch.as_tensor(act, **f).reshape(-1)
+        self.side["rew"][a:b] = torch.as_tensor(rew, **f).reshape(-1)
+        self.side["obs2"][a:b] = torch.as_tensor(obs2, **f).reshape(-1, self.obs.shape[2])
+        self.side["done"][a:b] = torch.as_tensor(np.asarray(done).astype(np.uint8) if not torch.is_tensor(done) else done,
+                                                 device=self.device).to(torch.uint8).reshape(-1)
+        self.side_count = b
+        self.side_epoch += 1
+        return k
+
+    def _side_struct(self):
+        from ddpg_trucktrailer_amd import _lib as L
+        if self.side is None or self.side_count == 0:
+            return None
+        sd = self.side
+        return L.TTSideBuffer(sd["obs"].data_ptr(), sd["act"].data_ptr(), sd["rew"].data_ptr(), sd["obs2"].data_ptr(),
+                              sd["done"].data_ptr(), int(self.side_count), 0)
+
+    # ---- checkpoint ----------------------------------------------------------------------------------------
+    def state_dict(self, with_replay=True):
+        sd = {"k": int(self.k), "slots": int(self.slots), "n": int(self.n), "side_count": int(self.side_count)}
+        if with_replay:
+            sd.update(obs=self.obs.cpu(), act=self.act.cpu(), rew=self.rew.cpu(), done=self.done.cpu())
+            if self.side is not None:
+                sd["side"] = {k: v.cpu() for k, v in self.side.items()}
+        return sd
+
+    def load_state_dict(self, sd):
+        assert (int(sd["slots"]), int(sd["n"])) == (self.slots, self.n), "replay ring geometry differs"
+        if "obs" in sd:
+            self.obs.copy_(sd["obs"]); self.act.copy_(sd["act"]); self.rew.copy_(sd["rew"]); self.done.copy_(sd["done"])
+            if "side" in sd:
+                cap = sd["side"]["act"].shape[0]
+                if self.side is None or self.side["act"].shape[0] != cap:
+                    self.side = {k: v.to(self.device).clone() for k, v in sd["side"].items()}
+                else:
+                    for k, v in sd["side"].items():
+                        self.side[k].copy_(v)
+                self.side_count = int(sd.get("side_count", 0))
+                self.side_epoch += 1
+        self.k = int(sd["k"])               # the counters come back whether or not the contents did
+        self.k_dev.fill_(self.k)
+
     def sample_fused(self, batch_size, seed=0, return_index=False, done_as_bool=True):
         """sample() as ONE HIP launch (tt_ring_sample): Philox indices keyed by (seed, k_dev) + gather.
         done_as_bool=False returns the raw uint8 flags (no conversion launch; what the fused learner takes)."""
@@ -100,8 +166,10 @@ class TrajectoryRing:
                           torch.empty((batch_size, 2), dtype=torch.int32, device=self.device))
         s, a, r, s2, dn, idx = self._bufs
         p = lambda t: C.c_void_p(t.data_ptr())
+        side = self._side_struct()
         L.check(L.load().tt_ring_sample(batch_size, self.n, self.slots, p(self.k_dev), p(self.obs), p(self.act), p(self.rew),
-                                        p(self.done), int(seed) & (2 ** 64 - 1), p(s), p(a), p(r), p(s2), p(dn), p(idx),
+                                        p(self.done), int(seed) & (2 ** 64 - 1), C.byref(side) if side is not None else None,
+                                        p(s), p(a), p(r), p(s2), p(dn), p(idx),
                                         C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         out = (s, a, r, s2, dn.bool() if done_as_bool else dn)
         return out + (idx,) if return_index else out
@@ -116,4 +184,14 @@ class TrajectoryRing:
         t = torch.remainder(self.k_dev - 1 - back, self.slots)
         n = (u[1] * self.n).long().clamp_(max=self.n - 1)
         t1 = torch.remainder(t + 1, self.slots)
-        return (self.obs[t, n], self.act[t, n].unsqueeze(1), self.rew[t, n], self.obs[t1, n], self.done[t, n].bool())
+        out = [self.obs[t, n], self.act[t, n].unsqueeze(1), self.rew[t, n], self.obs[t1, n], self.done[t, n].bool()]
+        if self.side is not None and self.side_count > 0:      # the same mixed uniform draw as tt_ring_sample
+            m = self.side_count
+            in_ring = (avail * self.n).to(torch.float64)
+            pick = torch.rand(batch_size, device=dev, generator=generator, dtype=torch.float64) * (in_ring + m) < m
+            j = (torch.rand(batch_size, device=dev, generator=generator) * m).long().clamp_(max=m - 1)
+            sd = self.side
+            for i, src in enumerate((sd["obs"][j], sd["act"][j].unsqueeze(1), sd["rew"][j], sd["obs2"][j], sd["done"][j].bool())):
+                sel = pick.view(-1, *([1] * (src.dim() - 1)))
+                out[i] = torch.where(sel, src, out[i])
+        return tuple(out)

@@ -6,10 +6,15 @@ Per vector step, for all N envs of this rank at once:
     obs', r, done = env.step(scaled)               (HIP kernel; finished envs restart in-kernel)
     remember(obs, a, r, obs', done)                (a = the UNCLIPPED noisy action, trainv2.py:525):
                                                    obs', r, done are written by the kernel straight into the ring
-    learn()                                        (one gradient step, batch from the ring)
-Everything stays on the device.  run(k) replays hipGraphs of `graph_steps` WHOLE vector steps (policy, env step and
-learn(): about ten launches per step, back to back with no host in between); step() is the same vector step launched
-eagerly, with learn() alone captured (sampling included).  Both give the same bits."""
+    learn() x updates_per_step                     (gradient steps, each on a fresh batch from the ring)
+Everything stays on the device.  run(k) replays hipGraphs of whole vector steps (policy, env step and learn(): about ten
+launches per step, back to back with no host in between): graphs of `graph_steps` steps where the ring position allows
+it, single-step graphs for every other position, so that no step of a run() is launched eagerly whatever k and the
+position are.  step() is the same vector step launched eagerly, with learn() alone captured (sampling included).  All of
+them give the same bits.
+
+Data-parallel ranks (one process per GPU): a step is three graph segments with the two gradient all-reduces of
+DDPG_agent.py:95-104 between them, launched eagerly on RCCL (the collectives are not captured)."""
 import math
 import os
 
@@ -25,21 +30,31 @@ from ddpg_trucktrailer_amd.replay_buffer import TrajectoryRing
 # every launch of a capture comes from the capturing thread; "thread_local" keeps another thread's runtime calls (the
 # collective library's watchdog, a data loader) from invalidating it
 _CAPTURE_MODE = "thread_local"
+_SEED_STRIDE = 0x9E3779B97F4A7C15     # sampling key of update u of a vector step = seed + u * stride (mod 2^64)
+_MAX_GRAPH_SLOTS = 1024               # whole-step graphs exist per ring position: not for rings of a million slots
 
 
 class DDPGRollout:
     def __init__(self, env, batch_size=256, replay_slots=64, seed=27, alpha=1e-4, beta=1e-3, tau=1e-3, gamma=0.99,
-                 fc1_dims=400, fc2_dims=300, world_size=1, use_graph=True, agent=None, fused_learn=True, graph_steps=4):
+                 fc1_dims=400, fc2_dims=300, world_size=1, use_graph=True, agent=None, fused_learn=True, graph_steps=4,
+                 updates_per_step=1, data_parallel=None):
+        """updates_per_step: learn() calls per vector step (the reference does one per ENV step, trainv2.py:520-528; one
+        per vector step is 1/N of that -- the knob moves the data/update ratio back towards the reference's).
+        data_parallel: None = (world_size > 1); True forces the data-parallel launch structure with the process group's
+        real collectives even at world size 1 (tests of the RCCL path on one GPU)."""
         self.env, self.n, self.device = env, env.n_envs, env.device
         self.batch_size = batch_size
+        self.updates_per_step = int(updates_per_step)
+        assert self.updates_per_step >= 1
         torch.manual_seed(seed)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
+        self.dp = (world_size > 1) if data_parallel is None else bool(data_parallel)
         self.agent = agent if agent is not None else Agent(
             alpha=alpha, beta=beta, input_dims=(env.observation_dim,), tau=tau, n_actions=1, gamma=gamma,
             fc1_dims=fc1_dims, fc2_dims=fc2_dims, batch_size=batch_size, device=self.device,
             capturable=use_graph, replay=False)
-        if world_size > 1:
+        if self.dp:
             self.agent.enable_data_parallel()
         self.ring = TrajectoryRing(self.n, replay_slots, env.observation_dim, self.device)
         if self.device.type == "cuda":
@@ -58,10 +73,9 @@ class DDPGRollout:
             from ddpg_trucktrailer_amd.fused_learn import FusedLearner
             self.learner = FusedLearner(self.agent, batch_size)
             self.agent.fused_learner = self.learner
-            if world_size > 1:
+            if self.dp:
                 self.learner.enable_data_parallel()
         self.use_graph = use_graph and self.device.type == "cuda"
-        self.dp = world_size > 1
         if os.environ.get("TT_FORCE_DP") == "1" and self.learner is not None and not self.dp:
             # measurement aid: the data-parallel launch structure (three graph segments, separate Adam launches) on ONE
             # rank with no-op collectives -- what a rank's step costs before any time on the wire
@@ -70,12 +84,16 @@ class DDPGRollout:
         self.graph = None
         self.vector_steps = 0
         # whole-step graphs: the ring slots a step touches depend on k mod slots only, so a graph of G steps captured at
-        # ring position c*G is valid whenever k = c*G (mod slots): slots/G graphs cover the cycle
-        self.graph_steps = int(graph_steps) if (self.use_graph and self.learner is not None and graph_steps
-                                                and replay_slots % int(graph_steps) == 0) else 0
-        if self.dp and self.graph_steps:
+        # ring position c*G is valid whenever k = c*G (mod slots): slots/G graphs cover the cycle, and one single-step
+        # graph per position covers everything else (unaligned starts, remainders)
+        ok = self.use_graph and self.learner is not None and graph_steps and replay_slots <= _MAX_GRAPH_SLOTS
+        self.graph_steps = int(graph_steps) if ok else 0
+        if self.graph_steps and (replay_slots % self.graph_steps or self.dp):
             self.graph_steps = 1        # data-parallel: a step is three graphs with the two gradient all-reduces between
-        self.step_graphs = None
+        self.step_graphs = None         # [slots / G] graphs of G steps (G > 1, one rank)
+        self.step_graphs1 = None        # [slots] single-step graphs (data-parallel: up to the critic's gradient)
+        self.dp_graphs = None
+        self._graph_epoch = None        # env.graph_epoch the captures were made under
 
     # -------------------------------------------------------------- acting
     @torch.no_grad()
@@ -94,34 +112,40 @@ class DDPGRollout:
         return self.scaled
 
     # -------------------------------------------------------------- learning
-    def _learn_once(self):
+    def _sample(self, u):
+        key = (self.seed + u * _SEED_STRIDE) & (2 ** 64 - 1)
         if self.device.type == "cuda":
-            s, a, r, s2, d = self.ring.sample_fused(self.batch_size, seed=self.seed, done_as_bool=self.learner is None)
-        else:
-            s, a, r, s2, d = self.ring.sample(self.batch_size)
+            return self.ring.sample_fused(self.batch_size, seed=key, done_as_bool=self.learner is None)
+        return self.ring.sample(self.batch_size)
+
+    def _learn_once(self, u=0):
+        s, a, r, s2, d = self._sample(u)
         if self.learner is not None:
             self.learner.learn_batch(s, a, r, s2, d)                      # raw uint8 done flags of the sample
         else:
             self.agent.learn_batch(s, a, r, s2, d)
 
+    def _learn_all(self):
+        for u in range(self.updates_per_step):
+            self._learn_once(u)
+
     def learn(self):
         if self.ring.k < 2:
             return
         if not self.use_graph or self.dp:      # (collectives are not captured)
-            return self._learn_once()
+            return self._learn_all()
+        self._check_epoch()
         if self.graph is None:
-            # warm up (allocator, Adam state, autograd's AccumulateGrad nodes) on the SAME side stream the
-            # capture then uses: a backward captured on another stream than the one those nodes were created
-            # on needs cross-stream syncs that break the capture
+            # warm up (allocator, Adam state) on the SAME side stream the capture then uses
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(3):
-                    self._learn_once()
+                    self._learn_once(0)
             side.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=side, capture_error_mode=_CAPTURE_MODE):
-                self._learn_once()
+                self._learn_all()
             torch.cuda.current_stream().wait_stream(side)
         self.graph.replay()
 
@@ -142,77 +166,160 @@ class DDPGRollout:
         self.vector_steps += 1
 
     # -------------------------------------------------------------- many vector steps
+    def invalidate_graphs(self):
+        """Drop every captured graph (they bake kernel arguments by value: the env's reset seed, per-env-goal mode and
+        pose pool, the ring's side-buffer count; ring and network addresses).  Called automatically when the env or the
+        ring reports a change of those (env.graph_epoch, ring.side_epoch)."""
+        self.graph = self.step_graphs = self.step_graphs1 = self.dp_graphs = None
+
+    def _check_epoch(self):
+        epoch = (getattr(self.env, "graph_epoch", 0), self.ring.side_epoch)
+        if self._graph_epoch != epoch:
+            if self._graph_epoch is not None:
+                self.invalidate_graphs()
+            self._graph_epoch = epoch
+
+    def _graphs_current(self):
+        self._check_epoch()
+        return self.step_graphs1 is not None
+
+    def _capture_whole_step(self, k, side):
+        """One captured vector step at ring position k (mod slots); data-parallel: up to the critic's gradient."""
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side, capture_error_mode=_CAPTURE_MODE):
+            self._capture_body(k)
+        return g
+
+    def _capture_body(self, k):
+        self._act_and_step(self.ring.slots + k)      # + slots: any k > 0 with this ring position
+        if self.dp:
+            s, a, r, s2, d = self._sample(0)
+            self.learner.phase_a(s, a, r, s2, d, fuse_adam=False)
+        else:
+            self._learn_all()
+
     def _capture_step_graphs(self):
         ring, G = self.ring, self.graph_steps
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
+        assert getattr(ring, "_bufs", None) is not None, "sample buffers must exist before a capture (run a step first)"
+        self.step_graphs1 = [self._capture_whole_step(pos, side) for pos in range(ring.slots)]
         self.step_graphs = []
-        for c in range(ring.slots // G):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side, capture_error_mode=_CAPTURE_MODE):
-                for i in range(G):
-                    self._act_and_step(ring.slots + c * G + i)      # + slots: any k > 0 with this ring position
-                    if self.dp:                                     # up to the critic's gradient; see _dp_step
-                        s, a, r, s2, d = ring.sample_fused(self.batch_size, seed=self.seed, done_as_bool=False)
-                        self.learner.phase_a(s, a, r, s2, d, fuse_adam=False)
-                    else:
-                        self._learn_once()
-            self.step_graphs.append(g)
+        if G > 1:
+            for c in range(ring.slots // G):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side, capture_error_mode=_CAPTURE_MODE):
+                    for i in range(G):
+                        self._capture_body(c * G + i)
+                self.step_graphs.append(g)
         if self.dp:
             s = ring._bufs[0]
-            self.dp_graphs = []
-            for fn in (lambda: self.learner.phase_b(s, separate_adam=True), self.learner.phase_c):
+            self.dp_graphs = {}
+            pieces = {"b": lambda: self.learner.phase_b(s, separate_adam=True), "c": self.learner.phase_c}
+            for u in range(1, self.updates_per_step):      # the further updates of a step: sample + up to the critic's gradient
+                pieces[("a", u)] = (lambda u=u: self.learner.phase_a(*self._sample(u), fuse_adam=False))
+            for name, fn in pieces.items():
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side, capture_error_mode=_CAPTURE_MODE):
                     fn()
-                self.dp_graphs.append(g)
+                self.dp_graphs[name] = g
         torch.cuda.current_stream().wait_stream(side)
 
     def _dp_step(self):
-        """One data-parallel vector step: three graph replays with the reference's two optimizer-site all-reduces
-        (DDPG_agent.py:95-104) between them, launched eagerly on the flat gradient buffers."""
-        self.step_graphs[self.ring.k % self.ring.slots].replay()
-        self.learner.grad_sync_critic()
-        self.dp_graphs[0].replay()
-        self.learner.grad_sync_actor()
-        self.dp_graphs[1].replay()
+        """One data-parallel vector step: three graph replays per update with the reference's two optimizer-site
+        all-reduces (DDPG_agent.py:95-104) between them, launched eagerly on the flat gradient buffers."""
+        self.step_graphs1[self.ring.k % self.ring.slots].replay()
+        for u in range(self.updates_per_step):
+            if u:
+                self.dp_graphs[("a", u)].replay()
+            self.learner.grad_sync_critic()
+            self.dp_graphs["b"].replay()
+            self.learner.grad_sync_actor()
+            self.dp_graphs["c"].replay()
+
+    def _try_capture(self):
+        try:
+            self._capture_step_graphs()
+            return True
+        except Exception as exc:        # capture refused (driver / library state): the eager path is the same bits.
+            import warnings             # (covers capture ERRORS only: a crash inside the runtime is not an exception)
+            warnings.warn(f"whole-step hipGraph capture failed ({exc!r}); continuing with eager steps")
+            self.invalidate_graphs()
+            self.graph_steps = 0
+            return False
 
     def prepare(self):
-        """Everything one-off that run() would otherwise do lazily inside the first calls (a few eager vector steps that
+        """Everything one-off that run() would otherwise do lazily inside its first calls (a few eager vector steps that
         warm up allocators / kernel attributes / Adam state, then the graph captures), so that a timed region holds
         steady-state steps only.  Advances the loop by 4 vector steps."""
-        while self.ring.k < 4 or (self.graph_steps and self.ring.k % self.graph_steps):
+        while self.ring.k < 4:
             self.step()
-        if self.graph_steps and self.step_graphs is None and self.ring._env_counts:
-            try:
-                self._capture_step_graphs()
-            except Exception as exc:
-                import warnings
-                warnings.warn(f"whole-step hipGraph capture failed ({exc!r}); continuing with eager steps")
-                self.step_graphs, self.graph_steps = None, 0
+        if self.graph_steps and self.ring._env_counts and not self._graphs_current():
+            self._try_capture()
 
     def run(self, k):
-        """k vector steps.  Whole-step hipGraphs whenever the ring position is a multiple of graph_steps and at least
-        graph_steps steps remain (after a few eager steps that warm everything up); eager step() otherwise."""
-        ring, G = self.ring, self.graph_steps
+        """k vector steps, every one a graph replay once the loop is warm (4 eager steps) when whole-step graphs are on:
+        graphs of graph_steps steps at aligned ring positions, single-step graphs elsewhere; eager step() otherwise."""
+        ring = self.ring
         while k > 0:
-            if G and k >= G and ring.k >= 4 and ring.k % G == 0 and ring._env_counts:
-                if self.step_graphs is None:
-                    try:
-                        self._capture_step_graphs()
-                    except Exception as exc:        # capture refused (driver / library state): the eager path is the same bits
-                        import warnings
-                        warnings.warn(f"whole-step hipGraph capture failed ({exc!r}); continuing with eager steps")
-                        self.step_graphs, self.graph_steps = None, 0
-                        G = 0
-                        continue
+            G = self.graph_steps
+            if G and ring.k >= 4 and ring._env_counts and (self._graphs_current() or self._try_capture()):
+                pos = ring.k % ring.slots
                 if self.dp:
                     self._dp_step()
+                    done = 1
+                elif G > 1 and k >= G and pos % G == 0:
+                    self.step_graphs[pos // G].replay()
+                    done = G
                 else:
-                    self.step_graphs[(ring.k % ring.slots) // G].replay()
-                ring.k += G                     # host mirror; the step kernels advanced k_dev
-                self.vector_steps += G
-                k -= G
+                    self.step_graphs1[pos].replay()
+                    done = 1
+                ring.k += done                  # host mirror; the step kernels advanced k_dev
+                self.vector_steps += done
+                k -= done
             else:
                 self.step()
                 k -= 1
+
+    # -------------------------------------------------------------- checkpoint / resume of the whole loop
+    def state_dict(self):
+        """Everything the next vector step depends on: the four networks, both optimizers' state (the
+        fused learner's flat Adam moments and step count, or the torch optimizers'), the env batch, the replay ring with
+        its counters, the OU state.  The RNG streams of the loop are counter-based (Philox keyed by seed and the
+        counters saved here), so there is no generator state to save."""
+        torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
+        ag = self.agent
+        sd = {"format": 2, "seed": int(self.seed), "vector_steps": int(self.vector_steps),
+              "batch_size": int(self.batch_size), "updates_per_step": self.updates_per_step,
+              "nets": {n: {k: v.detach().cpu().clone() for k, v in getattr(ag, n).state_dict().items()}
+                       for n in ("actor", "critic", "target_actor", "target_critic")},
+              "ring": self.ring.state_dict(), "ou": self.noise.x.detach().cpu().clone(),
+              "env": self.env.state_dict() if hasattr(self.env, "state_dict") else None}
+        if self.learner is not None:
+            sd["fused_adam"] = self.learner.state_dict()
+        else:
+            sd["optim"] = {"actor": ag.actor.optimizer.state_dict(), "critic": ag.critic.optimizer.state_dict()}
+        return sd
+
+    def load_state_dict(self, sd):
+        ag = self.agent
+        assert int(sd["batch_size"]) == int(self.batch_size), "batch size differs"
+        with torch.no_grad():
+            for n, net_sd in sd["nets"].items():
+                for k, v in getattr(ag, n).state_dict().items():      # in place: captured graphs keep the addresses
+                    v.copy_(net_sd[k].to(v.device))
+        if self.learner is not None and "fused_adam" in sd:
+            self.learner.load_state_dict(sd["fused_adam"])
+        elif "optim" in sd:
+            ag.actor.optimizer.load_state_dict(sd["optim"]["actor"])
+            ag.critic.optimizer.load_state_dict(sd["optim"]["critic"])
+            self.graph = None                                         # optimizer state tensors were replaced
+        self.ring.load_state_dict(sd["ring"])
+        self.noise.x.copy_(sd["ou"].to(self.noise.x.device))
+        if sd.get("env") is not None:
+            self.env.load_state_dict(sd["env"])                       # bumps env.graph_epoch: graphs are re-captured
+        if int(sd["seed"]) != int(self.seed):
+            self.invalidate_graphs()                                  # the Philox keys are kernel arguments
+        self.seed = int(sd["seed"])
+        self.vector_steps = int(sd["vector_steps"])
+        self.updates_per_step = int(sd.get("updates_per_step", self.updates_per_step))

@@ -48,6 +48,9 @@ class TruckTrailerVecEnv:
             self.done = torch.zeros(n, dtype=torch.uint8, device=self.device)
         self._info_bufs = None
         self.max_steer = float(self.params.max_steer)
+        # bumped whenever something a captured step launch bakes in BY VALUE changes (reset seed, per-env-goal mode, pose
+        # pool, step counter): holders of hipGraphs of step launches (DDPGRollout) re-capture when it moves
+        self.graph_epoch = 0
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
@@ -89,11 +92,13 @@ class TruckTrailerVecEnv:
         """Philox-sampled start poses for all (or masked) envs; returns obs [N,23]."""
         obs = self.obs if out is None else out
         m = self._as(mask, torch.uint8)
+        self.graph_epoch += 1
         self._check(self.lib.tt_env_reset(self._h, _ptr(m), int(seed) & (2 ** 64 - 1), _ptr(obs), self._stream()))
         return obs
 
     def set_reset_pool(self, poses):
         """Resets (explicit and in-kernel) draw start poses from this [m,3] pool (x, y, yaw) instead of the box."""
+        self.graph_epoch += 1
         if poses is None:
             self._pool = None
             self._check(self.lib.tt_env_set_reset_pool(self._h, None, 0))
@@ -109,6 +114,8 @@ class TruckTrailerVecEnv:
         L2 = self._as(L2, torch.float64, (k,)) if L2 is not None else None
         idx = self._as(idx, torch.int32, (k,)) if idx is not None else None
         obs = self.obs if out is None else out
+        if goal is not None or L2 is not None:
+            self.graph_epoch += 1          # switches the handle to per-env goals / trailer lengths
         self._check(self.lib.tt_env_set_pose(self._h, _ptr(idx), k, _ptr(start), _ptr(goal), _ptr(L2), _ptr(obs),
                                              self._stream()))
         return obs
@@ -124,6 +131,8 @@ class TruckTrailerVecEnv:
         goal = self._as(goal, torch.float64, (k, 3)) if goal is not None else None
         L2 = self._as(L2, torch.float64, (k,)) if L2 is not None else None
         idx = self._as(idx, torch.int32, (k,)) if idx is not None else None
+        if goal is not None or L2 is not None:
+            self.graph_epoch += 1
         self._check(self.lib.tt_env_set_attrs(self._h, _ptr(idx), k, _ptr(start), _ptr(goal), _ptr(L2), self._stream()))
 
     def set_state(self, state, idx=None):
@@ -135,6 +144,8 @@ class TruckTrailerVecEnv:
     def set_max_steps(self, max_steps, idx=None):
         m = self._as(max_steps, torch.int32).reshape(-1)
         k = m.shape[0]
+        if k and (int(m.min()) < 0 or int(m.max()) > L.MAX_EPISODE_STEPS):
+            raise ValueError(f"max_episode_steps must lie in [0, {L.MAX_EPISODE_STEPS}] (12-bit packed counters)")
         idx = self._as(idx, torch.int32, (k,)) if idx is not None else None
         self._check(self.lib.tt_env_set_max_steps(self._h, _ptr(idx), k, _ptr(m), self._stream()))
 
@@ -192,6 +203,7 @@ class TruckTrailerVecEnv:
         if counter is not None:
             assert counter.dtype == torch.int64 and counter.device == self.device and counter.numel() == 1
         self._step_counter = counter
+        self.graph_epoch += 1
         self._check(self.lib.tt_env_set_step_counter(self._h, _ptr(counter) if counter is not None else None))
 
     def step_random(self, policy_seed=123, auto_reset=True, info=False, action_out=None, obs_out=None, reward_out=None,
@@ -228,6 +240,7 @@ class TruckTrailerVecEnv:
     def load_state_dict(self, sd):
         blob = sd["blob"].to(self.device)
         meta = (C.c_uint64 * 4)(*sd["meta"])
+        self.graph_epoch += 1              # reset seed and per-env-goal mode come back with the blob
         self._check(self.lib.tt_env_import(self._h, _ptr(blob), C.byref(meta), self._stream()))
         torch.cuda.current_stream(self.device).synchronize()      # blob is a temporary
         if sd.get("pool") is not None:

@@ -28,8 +28,9 @@
 extern "C" {
 #endif
 
-#define TT_VERSION 1
+#define TT_VERSION 2
 #define TT_OBS_DIM 23 /* simv2.py:76 */
+#define TT_MAX_EPISODE_STEPS 4095 /* steps and max_episode_steps are 12-bit packed counters; larger values are TT_EINVAL */
 
 enum { TT_OK = 0, TT_EINVAL = -1, TT_ENOMEM = -2, TT_EHIP = -3, TT_ENODEV = -4 };
 
@@ -128,7 +129,9 @@ int tt_env_set_attrs(tt_env *env, const int32_t *idx, int k, const double *start
 int tt_env_set_state(tt_env *env, const int32_t *idx, int k, const double *state, tt_stream_t stream);
 int tt_env_get_state(tt_env *env, double *state_out, tt_stream_t stream);
 
-/* `env.max_episode_steps = ...` (heatmap.py:96) for envs idx[j]. */
+/* `env.max_episode_steps = ...` (heatmap.py:96) for envs idx[j].  Values outside [0, TT_MAX_EPISODE_STEPS] are refused
+ * with TT_EINVAL and nothing is written; to check them this call copies max_steps to the host and waits for `stream`
+ * (a setter, not a hot call; not capturable). */
 int tt_env_set_max_steps(tt_env *env, const int32_t *idx, int k, const int32_t *max_steps, tt_stream_t stream);
 
 /* Episode bookkeeping read-back; any pointer may be NULL.  steps/max_steps [N] i32;
@@ -220,10 +223,20 @@ int tt_actor_act(int n, const float *obs, const tt_mlp_weights *w, float *ou_sta
  * obs [slots,N,23] f32, act/rew [slots,N] f32, done [slots,N] u8 (transition (t,e) = obs[t][e], act[t][e], rew[t][e],
  * obs[t+1][e], done[t][e]); *k_dev = vector steps completed, read on the device, so a captured hipGraph draws new
  * indices at every replay.  Outputs: s_out, s2_out [batch,23], a_out, r_out [batch] f32, d_out [batch] u8,
- * idx_out [batch,2] i32 (slot, env) or NULL. */
+ * idx_out [batch,2] i32 (slot, env) or NULL.
+ * side (may be NULL): stand-alone transitions that are not part of any env's trajectory -- the expert tuples
+ * `(obs, action / radians(45), reward, obs_next, done)` that trainv2.py:457-466 re-inserts with agent.remember
+ * (produced by exp_gen.py:77-110).  They take part in the same uniform draw: with `count` side transitions and R
+ * intact ring transitions every one of the count + R has probability 1/(count + R); a side draw reports
+ * idx_out = (-1, j). */
+typedef struct tt_side_buffer {
+    const float *obs, *act, *rew, *obs2; /* [count,23], [count], [count], [count,23] f32 */
+    const uint8_t *done;                 /* [count] */
+    int32_t count, reserved_;
+} tt_side_buffer;
 int tt_ring_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const float *obs, const float *act,
-                   const float *rew, const uint8_t *done, uint64_t seed, float *s_out, float *a_out, float *r_out,
-                   float *s2_out, uint8_t *d_out, int32_t *idx_out, tt_stream_t stream);
+                   const float *rew, const uint8_t *done, uint64_t seed, const tt_side_buffer *side, float *s_out,
+                   float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out, tt_stream_t stream);
 
 /* CriticNetwork.forward (DDPG/networks.py:55-68) for n rows: q_out [n]. */
 int tt_critic_forward(int n, const float *obs /*[n,23]*/, const float *action /*[n]*/, const tt_mlp_weights *w,

@@ -95,11 +95,48 @@ def main():
 
     agent.memory.mem_cntr = B
     agent.memory.sample_buffer = lambda batch_size: (states, actions, rewards, states_, dones)
-    agent.learn()
+
+    # Gradients and losses of the reference's OWN learn() (DDPG_agent.py:95-104), observed without touching its code:
+    # each optimizer's step() is wrapped to copy every parameter's .grad first (the two sites of the data-parallel
+    # all-reduce), F.mse_loss / T.mean as seen from DDPG_agent are wrapped to record the two losses.
+    tap = {"n": 0}
+
+    def grab(net, name, orig):
+        def step(*a, **kw):
+            for k, p_ in net.named_parameters():
+                g = p_.grad.detach().cpu().numpy().copy()
+                if k == "fc2.weight":
+                    g = g.reshape(-1)[::SAMPLE_STRIDE].copy()
+                out[f"grad{tap['n']}/{name}/{k}"] = g
+            return orig(*a, **kw)
+        return step
+    agent.critic.optimizer.step = grab(agent.critic, "critic", agent.critic.optimizer.step)
+    agent.actor.optimizer.step = grab(agent.actor, "actor", agent.actor.optimizer.step)
+    orig_mse, orig_mean = mod.F.mse_loss, mod.T.mean
+
+    def mse(*a, **kw):
+        r = orig_mse(*a, **kw)
+        out[f"loss{tap['n']}/critic"] = np.float32(r.item())
+        return r
+
+    def mean(*a, **kw):
+        r = orig_mean(*a, **kw)
+        out[f"loss{tap['n']}/actor"] = np.float32(r.item())
+        return r
+
+    def learn_tapped():
+        tap["n"] += 1
+        mod.F.mse_loss, mod.T.mean = mse, mean
+        try:
+            agent.learn()
+        finally:
+            mod.F.mse_loss, mod.T.mean = orig_mse, orig_mean
+
+    learn_tapped()
     for name in ("actor", "critic", "target_actor", "target_critic"):
         sd(getattr(agent, name), f"after1/{name}", out)
-    agent.learn()
-    agent.learn()
+    learn_tapped()
+    learn_tapped()
     for name in ("actor", "critic", "target_actor", "target_critic"):
         sd(getattr(agent, name), f"after3/{name}", out)
 

@@ -156,3 +156,75 @@ def test_two_rank_loop_graphs_match_eager(tmp_path, gpu_device):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "ranks diverged"
     assert torch.equal(a[0], a[1]), "graph path differs from the eager path"
     assert torch.isfinite(a[0]).all()
+
+
+def _nccl_loop_worker(rank, world, port, out_dir):
+    """One rank per GPU on RCCL (backend "nccl"): the data-parallel vector loop, graph segments captured while the
+    communicator is alive, ReduceOp.AVG on the flat gradient buffers."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert dist.get_backend() == "nccl"
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    flats = []
+    # graphs + RCCL / everything eager + RCCL / (one rank only) the single-rank launch structure without collectives
+    variants = [dict(graph_steps=4, data_parallel=True), dict(graph_steps=0, data_parallel=True)]
+    if world == 1:
+        variants.append(dict(graph_steps=4, data_parallel=False))
+    for kw in variants:
+        env = TruckTrailerVecEnv(1024, device=dev)
+        env.reset(seed=27 + rank)
+        loop = DDPGRollout(env, batch_size=128, replay_slots=8, seed=27 + rank, world_size=world, **kw)
+        assert loop.dp == kw["data_parallel"]
+        loop.run(13)
+        torch.cuda.synchronize()
+        if kw["graph_steps"]:
+            assert loop.step_graphs1 is not None and (loop.dp_graphs is not None) == loop.dp
+        flats.append(torch.cat([p.detach().reshape(-1) for net in loop.agent._nets() for p in net.parameters()]).cpu())
+        env.close()
+    torch.save(flats, os.path.join(out_dir, f"nccl{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_world_size_1_loop_graphs_match_eager(tmp_path, gpu_device):
+    """The RCCL code path on ONE GPU: init_process_group("nccl", device_id=...), ReduceOp.AVG on the flat gradient
+    buffers, the three graph segments captured with a live communicator.  Graph path == eager path bit for bit, and
+    (AVG over one rank being the identity) == the single-rank loop whose Adam runs inside the weight-gradient launch."""
+    port = _free_port()
+    mp.start_processes(_nccl_loop_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True, start_method="spawn")
+    a = torch.load(tmp_path / "nccl0.pt", weights_only=True)
+    assert torch.isfinite(a[0]).all()
+    assert torch.equal(a[0], a[1]), "graph path differs from the eager path under RCCL"
+    assert torch.equal(a[0], a[2]), "data-parallel structure at world size 1 differs from the single-rank loop"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2])
+def test_rccl_n_rank_loop(tmp_path, gpu_device, world):
+    """One rank per device over RCCL/xGMI; skipped below `world` devices (the 1-GPU test box)."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    port = _free_port()
+    mp.start_processes(_nccl_loop_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    flats = [torch.load(tmp_path / f"nccl{r}.pt", weights_only=True) for r in range(world)]
+    for r in range(1, world):
+        assert torch.equal(flats[0][0], flats[r][0]) and torch.equal(flats[0][1], flats[r][1]), "ranks diverged"
+    assert torch.equal(flats[0][0], flats[0][1]), "graph path differs from the eager path"
+    assert torch.isfinite(flats[0][0]).all()
+
+
+def test_bench_refuses_fewer_gpus_than_ranks():
+    """`python bench.py --gpus N` starts N ranks itself; with fewer than N GPUs visible it prints no line and exits 2."""
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    have = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 3), "--steps", "4", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr and "{" not in r.stdout

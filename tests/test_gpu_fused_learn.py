@@ -97,6 +97,39 @@ def test_fused_learn_matches_reference_fixture_and_torch_path(gpu_device):
     assert int(fl2.step_dev.item()) == 3 and torch.equal(fl2.critic.m, fl.critic.m)
 
 
+def test_fused_gradients_and_losses_match_the_reference(gpu_device):
+    """FusedLearner's flat gradient buffers (what RCCL all-reduces) at both optimizer sites of learn() steps 1..3 against
+    the .grad the reference's own learn() held at its optimizer.step() calls (fixture F5 grad<i>/..., DDPG_agent.py:95-104),
+    3e-5 relative to each tensor's largest gradient; critic loss from the fused q / y, actor loss from Q(s, mu(s))."""
+    import torch
+    from conftest import GOLDEN
+    from ddpg_trucktrailer_amd.fused_learn import FusedLearner, _ORDER
+    from test_learner import _batch, _check_grads
+    z = np.load(os.path.join(GOLDEN, "f5_learner.npz"), allow_pickle=False)
+    agent = _agent(gpu_device, z)
+    s, a, r, s2, d = _batch(z, gpu_device)
+    d8 = d.to(torch.uint8)
+    fl = FusedLearner(agent, 256)
+
+    def named(st):
+        head = "q" if st.critic else "mu"
+        names = list(_ORDER) + [head + ".weight", head + ".bias"] + (["action_value.weight", "action_value.bias"] if st.critic else [])
+        return [(n, g.clone()) for n, g in zip(names, st.grads)]
+    for i in (1, 2, 3):
+        # the data-parallel pieces leave each site's gradient in place before its optimizer launch (phase_a / phase_b)
+        fl.phase_a(s, a, r, s2, d8, fuse_adam=False)
+        _check_grads(z, i, "critic", named(fl.critic))
+        loss_c = torch.mean((fl.q - fl.y) ** 2).item()
+        assert abs(loss_c - float(z[f"loss{i}/critic"])) <= 1e-5 * float(z[f"loss{i}/critic"])
+        fl.phase_b(s, separate_adam=True)
+        _check_grads(z, i, "actor", named(fl.actor))
+        loss_a = -fl.q_pi.mean().item()
+        assert abs(loss_a - float(z[f"loss{i}/actor"])) <= 2e-5 * max(0.1, abs(float(z[f"loss{i}/actor"])))
+        fl.phase_c()
+    from test_learner import _check_snapshot
+    _check_snapshot(agent, z, "after3", 4e-5)
+
+
 def test_fused_learn_in_hipgraph(gpu_device):
     """Captured once, replayed: every replay advances the step counter and keeps matching the eager fused path."""
     import torch

@@ -188,3 +188,156 @@ def test_whole_step_graphs_match_eager_steps(gpu_device):
     assert int(a.learner.step_dev.item()) == int(b.learner.step_dev.item()) >= k - 1    # learn() from the 2nd step on
     for lp in loops:
         lp.env.close()
+
+
+def _loop_flat(loop):
+    import torch
+    return torch.cat([p.detach().reshape(-1) for net in loop.agent._nets() for p in net.parameters()])
+
+
+def test_run_is_all_graph_replays_for_any_warmup_and_steps(gpu_device, monkeypatch):
+    """bench.py's driver form is --steps 20 --warmup 5: after prepare() no step of run() may be launched eagerly
+    whatever the ring position (single-step graphs cover unaligned positions and remainders), and the result is the
+    eager loop's, bit for bit."""
+    import torch
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    n = 1024
+    loops = []
+    for graph_steps in (4, 0):
+        env = TruckTrailerVecEnv(n)
+        env.reset(seed=9)
+        loops.append(DDPGRollout(env, batch_size=256, replay_slots=8, seed=9, use_graph=True, graph_steps=graph_steps))
+    a, b = loops
+    a.prepare()
+    assert a.ring.k == 4 and len(a.step_graphs1) == 8 and len(a.step_graphs) == 2
+
+    def no_eager():
+        raise AssertionError("run() launched a vector step eagerly")
+    monkeypatch.setattr(a, "step", no_eager)
+    a.run(5)            # warm-up of 5 from position 4: one 4-step graph + one single
+    a.run(20)           # position 9: single, single, single (to 12), four 4-step graphs, one single
+    a.run(3)
+    for _ in range(4 + 5 + 20 + 3):
+        b.step()
+    torch.cuda.synchronize()
+    assert a.ring.k == b.ring.k == 32 and int(a.ring.k_dev.item()) == 32
+    assert torch.equal(_loop_flat(a), _loop_flat(b))
+    for name in ("obs", "act", "rew", "done"):
+        assert torch.equal(getattr(a.ring, name), getattr(b.ring, name)), name
+    assert torch.equal(a.env.state, b.env.state)
+    for lp in loops:
+        lp.env.close()
+
+
+def test_updates_per_step(gpu_device):
+    """updates_per_step = 3: three learn() calls per vector step, each on its own batch; graphs == eager."""
+    import torch
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    loops = []
+    for graph_steps in (4, 0):
+        env = TruckTrailerVecEnv(512)
+        env.reset(seed=3)
+        loops.append(DDPGRollout(env, batch_size=64, replay_slots=8, seed=3, graph_steps=graph_steps, updates_per_step=3))
+    a, b = loops
+    a.run(14)
+    for _ in range(14):
+        b.step()
+    torch.cuda.synchronize()
+    assert int(a.learner.step_dev.item()) == int(b.learner.step_dev.item()) == 3 * 13      # learn() from the 2nd step on
+    assert torch.equal(_loop_flat(a), _loop_flat(b))
+    s0 = a._sample(0)[0].clone(); s1 = a._sample(1)[0].clone()
+    assert not torch.equal(s0, s1), "the updates of one vector step must draw different batches"
+    for lp in loops:
+        lp.env.close()
+
+
+def test_torch_learn_path_captured_equals_eager(gpu_device):
+    """DDPGRollout(fused_learn=False): learn() through torch autograd, captured into a hipGraph.  A clone of a parameter
+    that still carries its grad_fn, made on ANOTHER stream, keeps that parameter's AccumulateGrad node pinned there --
+    the situation in which a captured backward() used to fork the capture and crash HIP's EndCapture; learn_batch takes
+    its gradients from torch.autograd.grad, which does not go through those nodes."""
+    import torch
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    loops = []
+    for use_graph in (True, False):
+        env = TruckTrailerVecEnv(256)
+        env.reset(seed=4)
+        loop = DDPGRollout(env, batch_size=64, replay_slots=8, seed=4, use_graph=use_graph, fused_learn=False)
+        assert loop.learner is None
+        loops.append(loop)
+    a, b = loops
+    keep = [p.clone() for p in a.agent.critic.parameters()] + [p.clone() for p in a.agent.actor.parameters()]
+    assert all(k.grad_fn is not None for k in keep)
+    for _ in range(9):
+        a.step(); b.step()
+    torch.cuda.synchronize()
+    assert a.graph is not None and b.graph is None
+    for x, y in zip(_loop_flat(a).split(4096), _loop_flat(b).split(4096)):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-7)
+    assert torch.isfinite(_loop_flat(a)).all()
+    del keep
+    for lp in loops:
+        lp.env.close()
+
+
+def test_whole_loop_resume_is_bitwise(gpu_device, tmp_path):
+    """save after 10 vector steps, continue 9 more; a FRESH loop that loads the file and runs the same 9
+    steps ends bit-identical: env batch, ring + counters, OU state, all four networks, the fused Adam state."""
+    import torch
+    from ddpg_trucktrailer_amd import checkpoint
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+
+    def make(seed):
+        env = TruckTrailerVecEnv(1536)
+        env.reset(seed=seed)
+        return DDPGRollout(env, batch_size=128, replay_slots=8, seed=seed, graph_steps=4)
+    a = make(21)
+    a.run(10)
+    path = checkpoint.save_loop_checkpoint(str(tmp_path / "loop.pt"), a, training_state={"episode_num": 7})
+    a.run(9)
+    b = make(99)                       # different seed, different poses, different weights: all must come from the file
+    b.run(6)                           # ... and its graphs are already captured when the file is loaded
+    ts = checkpoint.load_loop_checkpoint(path, b)
+    assert ts == {"episode_num": 7} and b.ring.k == 10 and b.vector_steps == 10
+    b.run(9)
+    torch.cuda.synchronize()
+    assert torch.equal(_loop_flat(a), _loop_flat(b))
+    for name in ("obs", "act", "rew", "done"):
+        assert torch.equal(getattr(a.ring, name), getattr(b.ring, name)), name
+    assert torch.equal(a.noise.x, b.noise.x) and torch.equal(a.env.state, b.env.state)
+    assert int(a.ring.k_dev.item()) == int(b.ring.k_dev.item()) == 19
+    for st_a, st_b in ((a.learner.actor, b.learner.actor), (a.learner.critic, b.learner.critic)):
+        assert torch.equal(st_a.m, st_b.m) and torch.equal(st_a.v, st_b.v)
+    assert int(a.learner.step_dev.item()) == int(b.learner.step_dev.item())
+    ea, eb = a.env.episode(), b.env.episode()
+    assert torch.equal(ea["steps"], eb["steps"]) and torch.equal(ea["start"], eb["start"])
+    a.env.close(); b.env.close()
+
+
+def test_whole_config3_loop_at_bench_size(gpu_device):
+    """BASELINE config 3 at its stated size (N = 65536, batch 256, 64-slot ring): 8 steps as graphs == 8 eager steps,
+    finite weights, learn() really ran."""
+    import torch
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    n = 65536
+    flats = []
+    for graph_steps in (4, 0):
+        env = TruckTrailerVecEnv(n)
+        env.reset(seed=27)
+        loop = DDPGRollout(env, batch_size=256, replay_slots=64, seed=27, graph_steps=graph_steps)
+        w0 = _loop_flat(loop).clone()
+        loop.run(12)                   # 4 eager warm-up steps + 8
+        torch.cuda.synchronize()
+        flat = _loop_flat(loop)
+        assert torch.isfinite(flat).all() and not torch.equal(flat, w0)
+        assert torch.isfinite(loop.ring.rew[:12]).all() and int(loop.learner.step_dev.item()) == 11
+        flats.append((flat.clone(), loop.ring.obs[:13].clone(), loop.env.state.clone()))
+        env.close()
+        del loop
+    for x, y in zip(*flats):
+        assert torch.equal(x, y)

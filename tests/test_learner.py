@@ -77,6 +77,53 @@ def test_learn_matches_reference_cpu():
     _run_learner_parity(torch.device("cpu"))
 
 
+def _check_grads(z, step, name, named_grads, rtol=3e-5):
+    """Gradients against the reference's own learn() at its optimizer.step() sites (fixture F5 grad<step>/...):
+    rtol relative to each tensor's largest gradient, + 1e-7 absolute.  Adam's first step is +-lr whatever the
+    gradient's size, so the after1 weights pin gradient SIGNS only; this pins the magnitudes."""
+    stride = int(z["sample_stride"])
+    for k, g in named_grads:
+        got = g.detach().cpu().numpy()
+        if k == "fc2.weight":
+            got = got.reshape(-1)[::stride]
+        ref = z[f"grad{step}/{name}/{k}"]
+        assert got.shape == ref.shape, (name, k)
+        tol = rtol * np.abs(ref).max() + 1e-7
+        err = np.abs(got - ref).max()
+        assert err <= tol, (step, name, k, err, tol)
+
+
+def _run_gradient_parity(device):
+    """The torch path's gradients and losses at both optimizer sites of learn() steps 1..3, against the reference's."""
+    z = np.load(F5, allow_pickle=False)
+    agent = _agent(device)
+    _load_init(agent, z)
+    batch = _batch(z, device)
+    seen = {}
+    for net, name in ((agent.critic, "critic"), (agent.actor, "actor")):
+        orig = net.optimizer.step
+
+        def step(*a, _net=net, _name=name, _orig=orig, **kw):
+            seen[_name] = [(k, p.grad.clone()) for k, p in _net.named_parameters()]
+            return _orig(*a, **kw)
+        net.optimizer.step = step
+    for i in (1, 2, 3):
+        agent.learn_batch(*batch)
+        _check_grads(z, i, "critic", seen["critic"])
+        _check_grads(z, i, "actor", seen["actor"])
+        assert abs(float(agent.last_critic_loss) - float(z[f"loss{i}/critic"])) <= 1e-5 * float(z[f"loss{i}/critic"])
+        assert abs(float(agent.last_actor_loss) - float(z[f"loss{i}/actor"])) <= 2e-5 * max(0.1, abs(float(z[f"loss{i}/actor"])))
+
+
+def test_gradients_and_losses_match_reference_cpu():
+    _run_gradient_parity(torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_gradients_and_losses_match_reference_gpu(gpu_device):
+    _run_gradient_parity(gpu_device)
+
+
 @pytest.mark.gpu
 def test_learn_matches_reference_gpu(gpu_device):
     _run_learner_parity(gpu_device)

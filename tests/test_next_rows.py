@@ -165,3 +165,83 @@ def test_grid_evaluation_matches_single_env_episodes(gpu_device):
                 k += 1
             assert abs(reward_grid[iy, ix] - np.mean(scores)) <= 1e-4 * max(1.0, abs(np.mean(scores)))
     env.close()
+
+
+@pytest.mark.gpu
+def test_expert_transitions_into_the_vector_loop_ring(gpu_device):
+    """SURVEY 8f-4 on the replay the N-env loop actually samples: the reference re-inserts stored expert transitions one
+    `agent.remember` at a time (trainv2.py:457-466) into the buffer it then samples uniformly (replay_buffer.py:23-34).
+    Here they go into the TrajectoryRing's side buffer in bulk, and tt_ring_sample draws uniformly over ring + side
+    transitions.  Checked against that remember loop: same stored tuples, every side draw an intact tuple, the expected
+    share of side draws, and learn() runs on them from step 0 on."""
+    import torch
+    from ddpg_trucktrailer_amd import expert
+    from ddpg_trucktrailer_amd.agent import Agent
+    from ddpg_trucktrailer_amd.replay_buffer import TrajectoryRing
+    rng = np.random.RandomState(0)
+    episodes = []
+    for e in range(5):                                   # exp_gen.py:77-110: (obs, action / rad45, reward, obs', done)
+        ep = []
+        for t in range(40 + e):
+            ep.append((rng.uniform(-1, 1, 23).astype(np.float32), np.array([rng.uniform(-1, 1)], np.float32),
+                       float(rng.normal()), rng.uniform(-1, 1, 23).astype(np.float32), t == 39 + e))
+        episodes.append(ep)
+    m = sum(len(ep) for ep in episodes)
+    # the reference's way: one remember() per tuple
+    agent = Agent(alpha=1e-4, beta=1e-3, input_dims=(23,), tau=1e-3, n_actions=1, batch_size=64, device=gpu_device,
+                  max_size=1000)
+    for ep in episodes:
+        for s, a, r, s2, d in ep:
+            agent.remember(s, a, r, s2, d)
+    n, slots, B = 256, 6, 4096
+    ring = TrajectoryRing(n, slots, 23, gpu_device)
+    assert expert.load_into_ring(ring, episodes) == m == agent.memory.mem_cntr
+    mem = agent.memory
+    assert torch.equal(ring.side["obs"][:m], mem.state_memory[:m]) and torch.equal(ring.side["obs2"][:m], mem.new_state_memory[:m])
+    assert torch.equal(ring.side["act"][:m], mem.action_memory[:m, 0]) and torch.equal(ring.side["rew"][:m], mem.reward_memory[:m])
+    assert torch.equal(ring.side["done"][:m].bool(), mem.terminal_memory[:m])
+    # empty ring: every draw is a side transition, intact and uniform
+    s, a, r, s2, d, idx = ring.sample_fused(B, seed=1, return_index=True)
+    assert (idx[:, 0] == -1).all()
+    j = idx[:, 1].long()
+    assert torch.equal(s, mem.state_memory[j]) and torch.equal(s2, mem.new_state_memory[j]) and torch.equal(r, mem.reward_memory[j])
+    assert torch.equal(a, mem.action_memory[j]) and torch.equal(d, mem.terminal_memory[j])
+    hist = torch.bincount(j // 21, minlength=10).float()[:10] / B
+    assert (hist - 21 / m).abs().max() < 0.03
+    # ring with 3 intact steps: side share = m / (m + 3 n); ring draws untouched by the side buffer
+    for k in range(3):
+        ring.act[ring.slot()] = 1000.0 + k
+        ring.advance()
+    s, a, r, s2, d, idx = ring.sample_fused(B, seed=2, return_index=True)
+    side = idx[:, 0] == -1
+    share = side.float().mean().item()
+    assert abs(share - m / (m + 3 * n)) < 0.03, share
+    assert (a[~side, 0] >= 1000).all() and (a[side, 0].abs() <= 1).all()
+    assert torch.equal(s[side], mem.state_memory[idx[side, 1].long()])
+
+
+@pytest.mark.gpu
+def test_vector_loop_learns_from_expert_side_buffer(gpu_device):
+    """A DDPGRollout whose ring holds expert transitions: graphs captured before the load are re-captured (the side
+    count is a kernel argument), graphs == eager afterwards."""
+    import torch
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    rng = np.random.RandomState(1)
+    k = 500
+    tup = (rng.uniform(-1, 1, (k, 23)).astype(np.float32), rng.uniform(-1, 1, k).astype(np.float32),
+           rng.normal(size=k).astype(np.float32), rng.uniform(-1, 1, (k, 23)).astype(np.float32), rng.rand(k) < 0.05)
+    flats = []
+    for graph_steps in (4, 0):
+        env = TruckTrailerVecEnv(512)
+        env.reset(seed=6)
+        loop = DDPGRollout(env, batch_size=128, replay_slots=8, seed=6, graph_steps=graph_steps)
+        loop.run(8)
+        loop.ring.load_side(*tup)
+        loop.run(9)
+        torch.cuda.synchronize()
+        _, _, _, _, _, idx = loop.ring.sample_fused(4096, seed=11, return_index=True)
+        assert 0.05 < (idx[:, 0] == -1).float().mean().item() < 0.25          # 500 / (500 + 7*512) = 0.12
+        flats.append(torch.cat([p.detach().reshape(-1) for net in loop.agent._nets() for p in net.parameters()]).clone())
+        env.close()
+    assert torch.equal(flats[0], flats[1]) and torch.isfinite(flats[0]).all()

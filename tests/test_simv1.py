@@ -108,3 +108,55 @@ def test_simv1_facade(gpu_device):
     o, r, d, i = env.step(np.array([0.1], np.float32))
     assert isinstance(r, np.float64) and i["smoothness_penalty"] == 0
     env.close()
+
+
+@pytest.mark.gpu
+def test_simv1_at_bench_size(gpu_device):
+    """BASELINE config 5 at its stated size, N = 65536 (PARITY UNPINNED, see the module docstring): properties over all
+    envs -- the termination mask of simv1.py:432 (goal-passed / excessive-backward are reported but never end an
+    episode), the fixed 300-step cap, stateless reward, pool resets -- and the variant-1 C oracle on a 4096-env slice."""
+    import torch
+    from ddpg_trucktrailer_amd import _lib as L
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    from oracle import c_oracle
+    n, m = 65536, 4096
+    env = TruckTrailerVecEnv(n, variant=1)
+    pool = S.generate_pose_pool(512, seed=2)
+    env.set_reset_pool(pool)
+    env.reset(seed=3)
+    ep = env.episode()
+    assert (ep["max_episode_steps"] == 300).all()
+    start = ep["start"].cpu().numpy()
+    ora = c_oracle.COracle(m, variant=1)
+    ora.place(start[:m])
+    alive = np.ones(m, bool)
+    ended_by = np.zeros(8, np.int64)
+    masked_only = 0
+    for t in range(60):
+        a = env.random_actions(7, t)
+        obs, rew, done, info = env.step(a, auto_reset=False, info=True)
+        fl = info["flags"]
+        d = done.bool()
+        # done <=> a cause of the simv1 mask; the two unmasked causes alone never end an episode
+        assert torch.equal(d, (fl & L.default_params(1).term_mask) != 0)
+        masked_only += int(((fl & 0x30) != 0).logical_and((fl & 0x0F) == 0).sum())
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and (obs.abs() <= 1.0 + 1e-6).all()
+        o_obs, o_rew, o_done, o_info = ora.step(a[:m].cpu().numpy(), nthreads=8)
+        k = alive
+        assert np.abs(obs[:m].cpu().numpy()[k] - o_obs[k]).max() <= 1e-5
+        assert np.abs(info["comp"][:, :m].cpu().numpy().T[k] - o_info[k]).max() <= 1e-5
+        assert (d[:m].cpu().numpy()[k] == o_done[k]).all()
+        alive &= ~o_done
+        for b in range(7):
+            ended_by[b] += int(((fl >> b) & 1).logical_and(d).sum())
+    assert masked_only > 0, "the run must contain steps where only an unmasked cause fired"
+    assert ended_by[0] > 0 and ended_by[1] > 0            # jackknife and out-of-map both occur under the random policy
+    assert (info["comp"][L.INFO_ROWS.index("smoothness_penalty")] == 0).all()
+    # auto-reset at full size draws from the pool
+    env.reset(seed=4)
+    for t in range(40):
+        env.step(env.random_actions(8, t), auto_reset=True)
+    key = {tuple(r) for r in pool.round(12)}
+    st = env.episode()["start"].cpu().numpy()
+    assert all(tuple(r) in key for r in st[::97].round(12))
+    env.close()
