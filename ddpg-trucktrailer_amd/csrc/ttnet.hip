@@ -316,7 +316,7 @@ template <bool CRITIC>
 int launch(int n, const float *obs, const float *action, const tt_mlp_weights *w, float *out, const ActArgs &act,
            hipStream_t stream) {
     if (use_split(n, w)) {
-        const int rc = split_pack(w, w->split_ws, stream);
+        const int rc = split_pack(w, CRITIC, w->split_ws, stream);
         return rc != TT_OK ? rc : split_forward(CRITIC, n, obs, action, w, out, act, stream);
     }
     static bool attr2[64] = {};     // per device

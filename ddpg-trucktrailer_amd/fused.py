@@ -38,7 +38,7 @@ def weights_of(net):
     if hasattr(net, "action_value"):
         w.wa, w.ba = net.action_value.weight.data_ptr(), net.action_value.bias.data_ptr()
     w.in_dim, w.fc1_dims, w.fc2_dims = 23, 400, 300
-    # workspace of the split-bf16 kernel (csrc/ttnet_split.hip), re-packed from fc2 by every call that uses it; one per
+    # workspace of the split-f16 kernel (csrc/ttnet_split.hip), re-packed from the weights by every call that uses it; one per
     # module, so two streams never share one (the learner's side stream runs other modules)
     net._tt_split_ws = torch.empty(int(L.load().tt_mlp_split_ws_bytes()), dtype=torch.uint8, device=net.fc2.weight.device)
     w.split_ws = net._tt_split_ws.data_ptr()
@@ -92,8 +92,8 @@ def actor_act(net, obs, ou_state, act_raw, act_scaled, seed, step=0, step_dev=No
 def policy_kernel_info(n):
     """What the N-env policy forward executes on the matrix cores, for bench.py's roofline_mfma object."""
     waves = 4 * ((n + 127) // 128)
-    return {"kernel": "k_split_pack + k_mlp_split (choose_action for N envs)",
-            # v_mfma_f32_32x32x16_bf16: 25 k16 steps x 10 tiles x 6 products per wave, 32768 FLOP each
-            "mfma_flop": waves * 1500 * 32768.0,
-            "note": "bf16 MFMA FLOP executed (six bf16 products per f32 product block) over the dense bf16 peak; layer 1 "
-                    "(f32 MFMA, 2 % of the FLOP) not counted; algorithmic_* = the network's useful f32 FLOP"}
+    return {"kernel": "k_split_pack + k_mlp_split (choose_action for N envs; split-f16)",
+            # v_mfma_f32_32x32x16_f16, 32768 FLOP each: layer 2 = 25 k16 steps x 10 tiles x 3 products, layer 1 = 2 x 13 x 3
+            "mfma_flop": waves * (750 + 78) * 32768.0,
+            "note": "f16 MFMA FLOP executed (three f16 products per f32 product block, both layers) over the dense f16/bf16 "
+                    "peak; algorithmic_* = the network's useful f32 FLOP"}

@@ -82,6 +82,7 @@ class DDPGRollout:
             self.dp = True
             self.learner.grad_sync_critic = self.learner.grad_sync_actor = lambda: None
         self.graph = None
+        self._learn_side, self._learn_warm = None, 0
         self.vector_steps = 0
         # whole-step graphs: the ring slots a step touches depend on k mod slots only, so a graph of G steps captured at
         # ring position c*G is valid whenever k = c*G (mod slots): slots/G graphs cover the cycle, and one single-step
@@ -136,13 +137,20 @@ class DDPGRollout:
             return self._learn_all()
         self._check_epoch()
         if self.graph is None:
-            # warm up (allocator, Adam state) on the SAME side stream the capture then uses
-            side = torch.cuda.Stream(device=self.device)
+            # The first calls run eagerly -- they ARE the updates of their vector steps, so a captured loop makes exactly
+            # the updates an eager one makes -- on the side stream the capture then uses; they create everything a
+            # capture must not (allocator blocks, the torch optimizers' state, kernel attributes).  The next call is
+            # captured (a capture executes nothing) and replayed.
+            if self._learn_side is None:
+                self._learn_side = torch.cuda.Stream(device=self.device)
+            side = self._learn_side
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    self._learn_once(0)
-            side.synchronize()
+            if self._learn_warm < 3:
+                self._learn_warm += 1
+                with torch.cuda.stream(side):
+                    self._learn_all()
+                torch.cuda.current_stream().wait_stream(side)
+                return
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=side, capture_error_mode=_CAPTURE_MODE):
                 self._learn_all()

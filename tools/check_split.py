@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""GPU: the split-bf16 forward (csrc/ttnet_split.hip) against the exact-f32 kernel and torch, and its time."""
+"""GPU: the split-f16 forward (csrc/ttnet_split.hip) against the exact-f32 kernel, torch and torch-in-f64, its time, and
+the corner cases of the two-piece f16 split (tiny weights/activations whose `m` piece is subnormal, large ones near the
+stated range)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,14 +9,19 @@ from ddpg_trucktrailer_amd import fused
 from ddpg_trucktrailer_amd.networks import ActorNetwork, CriticNetwork
 
 dev = torch.device("cuda:0")
-torch.manual_seed(0)
-a = ActorNetwork(1e-4, (23,), 400, 300, 1, name="actor", device=dev)
-c = CriticNetwork(1e-3, (23,), 400, 300, 1, name="critic", device=dev)
-with torch.no_grad():
-    for net in (a, c):
-        net.bn1.weight.uniform_(0.5, 1.5); net.bn1.bias.uniform_(-0.3, 0.3)
-        net.bn2.weight.uniform_(0.5, 1.5); net.bn2.bias.uniform_(-0.3, 0.3)
-    a.mu.weight.uniform_(-0.2, 0.2); c.q.weight.uniform_(-0.2, 0.2)
+
+
+def nets(seed=0, wscale=1.0):
+    torch.manual_seed(seed)
+    a = ActorNetwork(1e-4, (23,), 400, 300, 1, name="actor", device=dev)
+    c = CriticNetwork(1e-3, (23,), 400, 300, 1, name="critic", device=dev)
+    with torch.no_grad():
+        for net in (a, c):
+            net.bn1.weight.uniform_(0.5, 1.5); net.bn1.bias.uniform_(-0.3, 0.3)
+            net.bn2.weight.uniform_(0.5, 1.5); net.bn2.bias.uniform_(-0.3, 0.3)
+            net.fc2.weight.mul_(wscale); net.fc1.weight.mul_(wscale)
+        a.mu.weight.uniform_(-0.2, 0.2); c.q.weight.uniform_(-0.2, 0.2)
+    return a, c
 
 
 def both(net, fn):
@@ -27,18 +34,28 @@ def both(net, fn):
     return out_split, out_f32
 
 
-for n in (1024, 1061, 5000, 65536):
-    obs = torch.rand((n, 23), device=dev) * 2 - 1
-    act = torch.rand((n, 1), device=dev) * 2.4 - 1.2
-    with torch.no_grad():
-        ref_mu, ref_q = a(obs), c(obs, act)
-        ref_mu64 = a.double()(obs.double()).float(); a.float()
-    s, f = both(a, lambda: fused.actor_forward(a, obs))
-    print(f"n={n} actor : |split-f32| {(s-f).abs().max().item():.2e}  |split-torch| {(s-ref_mu).abs().max().item():.2e}  "
-          f"|f32-torch| {(f-ref_mu).abs().max().item():.2e}  vs f64: split {(s-ref_mu64).abs().max().item():.2e} f32 {(f-ref_mu64).abs().max().item():.2e} torch {(ref_mu-ref_mu64).abs().max().item():.2e}")
-    s, f = both(c, lambda: fused.critic_forward(c, obs, act))
-    print(f"n={n} critic: |split-f32| {(s-f).abs().max().item():.2e}  |split-torch| {(s-ref_q).abs().max().item():.2e}  "
-          f"|f32-torch| {(f-ref_q).abs().max().item():.2e}  (|q| max {ref_q.abs().max().item():.2f})")
+def report(a, c, tag, ns=(1024, 1061, 5000, 65536)):
+    for n in ns:
+        obs = torch.rand((n, 23), device=dev) * 2 - 1
+        act = torch.rand((n, 1), device=dev) * 2.4 - 1.2
+        with torch.no_grad():
+            ref_mu, ref_q = a(obs), c(obs, act)
+            ref_mu64 = a.double()(obs.double()).float(); a.float()
+            ref_q64 = c.double()(obs.double(), act.double()).float(); c.float()
+        s, f = both(a, lambda: fused.actor_forward(a, obs))
+        print(f"{tag} n={n} actor : |split-f32| {(s-f).abs().max().item():.2e}  vs f64: split {(s-ref_mu64).abs().max().item():.2e} "
+              f"f32-kernel {(f-ref_mu64).abs().max().item():.2e} torch {(ref_mu-ref_mu64).abs().max().item():.2e}  nan {int(torch.isnan(s).sum())}")
+        s, f = both(c, lambda: fused.critic_forward(c, obs, act))
+        print(f"{tag} n={n} critic: |split-f32| {(s-f).abs().max().item():.2e}  vs f64: split {(s-ref_q64).abs().max().item():.2e} "
+              f"f32-kernel {(f-ref_q64).abs().max().item():.2e} torch {(ref_q-ref_q64).abs().max().item():.2e}  (|q| max {ref_q.abs().max().item():.2f})")
+
+
+a, c = nets(0)
+report(a, c, "init-like")
+a2, c2 = nets(1, wscale=20.0)          # |w| up to ~1.2 (trained-network sizes)
+report(a2, c2, "w x20   ", ns=(5000,))
+a3, c3 = nets(2, wscale=1e-3)          # tiny weights: m pieces subnormal
+report(a3, c3, "w x1e-3 ", ns=(5000,))
 
 for n in (65536, 262144):
     obs = torch.rand((n, 23), device=dev); out = torch.empty(n, device=dev)
