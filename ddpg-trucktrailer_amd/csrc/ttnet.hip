@@ -339,6 +339,7 @@ extern "C" {
 
 #ifdef TT_STAMPS
 int tt_debug_nstamps(unsigned long long *out16) { return ttnet::split_debug_stamps(out16); }
+int tt_debug_bstamps(unsigned long long *out, int nblocks) { return ttnet::split_debug_block_stamps(out, nblocks); }
 #endif
 
 uint64_t tt_mlp_split_ws_bytes(void) { return (uint64_t)split_ws_bytes(); }

@@ -84,6 +84,7 @@ int split_forward(bool critic, int n, const float *obs, const float *action, con
                   const ActArgs &act, hipStream_t stream);
 #ifdef TT_STAMPS
 int split_debug_stamps(unsigned long long *out16);
+int split_debug_block_stamps(unsigned long long *out, int nblocks);
 #endif
 
 }  // namespace ttnet

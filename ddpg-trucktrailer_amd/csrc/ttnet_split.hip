@@ -23,7 +23,8 @@
 //
 //   workgroup = 4 waves = 128 envs (32 per wave); per wave: h1 = 13 tiles x 16 registers (f32), layer-2
 //   accumulators 10 tiles x 16 registers; fc2 is streamed once per workgroup, as pre-split f16 planes in MFMA
-//   fragment order, through a 3-deep LDS ring shared by the four waves (20 KB per k16 step), filled by LDS-DMA.
+//   fragment order, through a 7-slot LDS ring shared by the four waves (20 KB per k16 step), filled by LDS-DMA five
+//   steps ahead of its use.
 //   Layer 1 (K = 23 + the bias as a 24th input that is always 1) runs on the same three-product scheme from pre-split
 //   fc1 fragments, also brought into LDS by DMA.
 #include "ttnet_common.h"
@@ -31,9 +32,13 @@
 namespace ttnet {
 namespace {
 
-#ifdef TT_STAMPS   // diagnostic build only: clocks of workgroup 0 / thread 0 at the phase boundaries
+#ifdef TT_STAMPS   // diagnostic build only: clocks of thread 0 of every workgroup at the phase boundaries
 __device__ unsigned long long g_nstamps[16];
-#define NSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_nstamps[i] = wall_clock64(); g_nstamps[8 + i] = clock64(); } } while (0)
+__device__ unsigned long long g_bstamps[4096 * 8];      // [block][phase] wall clock (100 MHz); [block][7] = XCC id
+#define NSTAMP(i) do { if (threadIdx.x == 0) { const unsigned long long w_ = wall_clock64();                                \
+        if (blockIdx.x < 4096) { g_bstamps[blockIdx.x * 8 + (i)] = w_;                                                      \
+            if ((i) == 0) g_bstamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)); }     \
+        if (blockIdx.x == 0) { g_nstamps[i] = w_; g_nstamps[8 + i] = clock64(); } } } while (0)
 #else
 #define NSTAMP(i) do { } while (0)
 #endif
@@ -45,19 +50,28 @@ using h2 = __attribute__((ext_vector_type(2))) _Float16;
 constexpr int ROWS = 128, WROWS = 32;       // envs per workgroup / per wave
 constexpr int T1 = 13, H1P = 32 * T1;       // layer-1 neuron tiles (416 >= 400)
 constexpr int T2 = 10, H2P = 32 * T2;       // layer-2 neuron tiles (320 >= 300)
+#ifdef TT_DBG_STEPS                         // timing experiments only (wrong results): fewer k16 steps of layer 2
+constexpr int STEPS = TT_DBG_STEPS;
+#else
 constexpr int STEPS = H1 / 16;              // 25 k16 steps of layer 2
+#endif
+constexpr int STEPS_FULL = H1 / 16;         // the h1 pieces always cover all 25 steps
 constexpr int S1 = 2;                       // k16 steps of layer 1: inputs 0..22 = observation, 23 = 1 (bias), 24..31 = 0
 constexpr int PIECES = 2 * T2;              // one k16 step of packed fc2 = 10 tiles x 2 planes of 64 lanes x 16 B: 5 per wave
 constexpr int CHUNK_U4 = PIECES * 64;
 constexpr int CHUNK_BYTES = CHUNK_U4 * 16;  // 20,480
-constexpr int RING = 3;
-constexpr int RING_BYTES = RING * CHUNK_BYTES;                        // 61,440
+constexpr int RING = 7;                     // an LDS-DMA piece lands ~1 us after its issue, a step is consumed in ~0.5 us: the
+                                            // stream runs RING - 2 = 5 steps ahead of the step being consumed
+constexpr int AHEAD = RING - 2;
+constexpr int RING_BYTES = RING * CHUNK_BYTES;                        // 143,360
 constexpr int W1_PIECES = S1 * T1 * 2;      // 52 pieces of packed fc1: 13 per wave
-constexpr int W1_BYTES = W1_PIECES * 1024;  // 53,248
+constexpr int W1_BYTES = W1_PIECES * 1024;  // 53,248: lives in ring slots 2..4 until layer 1 is done
+constexpr int W1_OFF = 2 * CHUNK_BYTES;
+static_assert(W1_OFF + W1_BYTES <= AHEAD * CHUNK_BYTES, "packed fc1 must fit in the ring slots that are filled after layer 1");
 constexpr int VEC_FLOATS = 2 * H1P + 6 * H2P;                         // g1' | be1' | b2 | g2 | be2 | w3 | wa | ba = 2,752
 constexpr int VEC_PIECES = 12;              // 11,008 B padded to 12 KB: 3 DMA pieces per wave
 constexpr int VEC_BYTES = VEC_PIECES * 1024;
-constexpr int LDS_BYTES = RING_BYTES + W1_BYTES + VEC_BYTES;          // 126,976
+constexpr int LDS_BYTES = RING_BYTES + VEC_BYTES;                     // 155,648
 constexpr int WS_W2 = 0, WS_W1 = STEPS * CHUNK_BYTES, WS_VEC = WS_W1 + W1_BYTES, WS_BYTES = WS_VEC + VEC_BYTES;   // 577,536
 
 constexpr float SX = 16.f, SW = 64.f;       // operand scales (powers of two: exact)
@@ -143,9 +157,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
                                                       const unsigned char *__restrict__ ws, float *__restrict__ out,
                                                       const ActArgs act) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const uint4 *ring = reinterpret_cast<const uint4 *>(lds_raw);             // 3 x one k16 step of packed fc2
-    const uint4 *w1_s = reinterpret_cast<const uint4 *>(lds_raw + RING_BYTES);// packed fc1 [2][13][2][64]
-    const float *p1_s = reinterpret_cast<const float *>(lds_raw + RING_BYTES + W1_BYTES);   // g1' | be1'       [2][416]
+    const uint4 *ring = reinterpret_cast<const uint4 *>(lds_raw);             // RING x one k16 step of packed fc2
+    const uint4 *w1_s = reinterpret_cast<const uint4 *>(lds_raw + W1_OFF);    // packed fc1 [2][13][2][64] (in ring slots 2..4)
+    const float *p1_s = reinterpret_cast<const float *>(lds_raw + RING_BYTES);              // g1' | be1'       [2][416]
     const float *p2_s = p1_s + 2 * H1P;                                       // b2 | g2 | be2 | w3 | wa | ba [6][320]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,22 +185,32 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
     // ---- prologue: this lane's observation features first (ordinary loads: the compiler waits for them on its own
     // count), then packed fc1 + the per-neuron vectors, then k16 steps 0 and 1 of fc2 by DMA
     float xo[S1][8];                                                          // obs^T as the B operand: input 16 s + 8 h + j
+    // unconditional loads from clamped (always valid) addresses, selected afterwards: 16 loads in flight at once
+    // instead of 16 exec-masked round trips
+    const float *orow = obs + (size_t)(row < n ? row : n - 1) * IN;
 #pragma unroll
     for (int s = 0; s < S1; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 16 * s + 8 * h + j;
-            xo[s][j] = (k < IN && row < n) ? obs[(size_t)row * IN + k] : (k == IN ? 1.f : 0.f);
+            xo[s][j] = orow[k < IN ? k : IN - 1];
         }
 #pragma unroll
     for (int i = 0; i < W1_PIECES / 4; ++i)
-        dma_piece(ws + WS_W1 + (wave * (W1_PIECES / 4) + i) * 1024, lds_base + RING_BYTES + (wave * (W1_PIECES / 4) + i) * 1024);
+        dma_piece(ws + WS_W1 + (wave * (W1_PIECES / 4) + i) * 1024, lds_base + W1_OFF + (wave * (W1_PIECES / 4) + i) * 1024);
 #pragma unroll
     for (int i = 0; i < VEC_PIECES / 4; ++i)
         dma_piece(ws + WS_VEC + (wave * (VEC_PIECES / 4) + i) * 1024,
-                  lds_base + RING_BYTES + W1_BYTES + (wave * (VEC_PIECES / 4) + i) * 1024);
+                  lds_base + RING_BYTES + (wave * (VEC_PIECES / 4) + i) * 1024);
 #pragma unroll
     for (int i = 0; i < 10; ++i) chunk_issue_piece(i / 5, i % 5);
+#pragma unroll
+    for (int s = 0; s < S1; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * s + 8 * h + j;
+            xo[s][j] = k < IN ? (row < n ? xo[s][j] : 0.f) : (k == IN ? 1.f : 0.f);
+        }
     uint4 xb[S1][2];                                                          // the observation's h and m pieces
 #pragma unroll
     for (int s = 0; s < S1; ++s) {
@@ -215,6 +239,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
         }
     }
     NSTAMP(2);
+    // every wave is done with packed fc1: its slots now take k16 steps 2..5 of fc2 (they land during LayerNorm 1)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 10; i < 5 * (AHEAD + 1); ++i) chunk_issue_piece(i / 5, i % 5);
+    uint32_t hb[STEPS_FULL][4], mb[STEPS_FULL][4];
     // LayerNorm(400) (biased variance, eps 1e-5) on the SCALED pre-activations: mean and deviations scale with them,
     // 1/sigma absorbs the scale; then gamma*SX, beta*SX and ReLU give the layer-2 operand already scaled by SX.
     // Tile 12 holds neurons 384..399 in v < 8.
@@ -233,19 +262,23 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
             for (int v = 0; v < (t == T1 - 1 ? 8 : 16); ++v) { acc1[t][v] -= mean; ss = fmaf(acc1[t][v], acc1[t][v], ss); }
         const float var = (ss + __shfl_xor(ss, 32)) * (1.f / H1) * (UNSCALE * UNSCALE);
         const float rstd = rsqrtf(var + 1e-5f) * UNSCALE;
+        // gamma*SX, beta*SX, ReLU, then straight into the two f16 pieces layer 2 multiplies with: hb[s] / mb[s] are the
+        // B fragments (h, m planes) of k16 step s -- element j of lane half h is neuron 16 s + 8 (j >> 2) + 4 h + (j & 3),
+        // i.e. registers 8 (s & 1) .. + 7 of tile s >> 1, the order the packed fc2 fragments are laid out in
 #pragma unroll
         for (int t = 0; t < T1; ++t)
 #pragma unroll
             for (int i = 0; i < (t == T1 - 1 ? 2 : 4); ++i) {
                 const float4 g = *reinterpret_cast<const float4 *>(p1_s + 32 * t + 8 * i + 4 * h);
                 const float4 be = *reinterpret_cast<const float4 *>(p1_s + H1P + 32 * t + 8 * i + 4 * h);
-                acc1[t][4 * i] = fmaxf(fmaf(acc1[t][4 * i] * rstd, g.x, be.x), 0.f);
-                acc1[t][4 * i + 1] = fmaxf(fmaf(acc1[t][4 * i + 1] * rstd, g.y, be.y), 0.f);
-                acc1[t][4 * i + 2] = fmaxf(fmaf(acc1[t][4 * i + 2] * rstd, g.z, be.z), 0.f);
-                acc1[t][4 * i + 3] = fmaxf(fmaf(acc1[t][4 * i + 3] * rstd, g.w, be.w), 0.f);
+                const float y0 = fmaxf(fmaf(acc1[t][4 * i] * rstd, g.x, be.x), 0.f);
+                const float y1 = fmaxf(fmaf(acc1[t][4 * i + 1] * rstd, g.y, be.y), 0.f);
+                const float y2 = fmaxf(fmaf(acc1[t][4 * i + 2] * rstd, g.z, be.z), 0.f);
+                const float y3 = fmaxf(fmaf(acc1[t][4 * i + 3] * rstd, g.w, be.w), 0.f);
+                const int st = 2 * t + (i >> 1), e = 2 * (i & 1);             // k16 step, first of its two packed registers
+                split2(y0, y1, hb[st][e], mb[st][e]);
+                split2(y2, y3, hb[st][e + 1], mb[st][e + 1]);
             }
-#pragma unroll
-        for (int v = 8; v < 16; ++v) acc1[T1 - 1][v] = 0.f;                    // padding neurons 400..415 (their weights are 0 too)
     }
 
     NSTAMP(3);
@@ -257,16 +290,14 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
         for (int v = 0; v < 16; ++v) acc2[u][v] = 0.f;
     // Hand-pipelined issue order, pinned with sched_barrier(0) between every pair of instruction groups: each of the
     // three MFMAs of a tile is followed by one small job that issues while the matrix pipe is busy (an MFMA holds the
-    // wave's issue port for 8 of its 32 cycles) -- the two fragment reads of the NEXT tile, then in tiles 0..3 one
-    // pair of the next step's B-operand split, in tiles 5..9 one LDS-DMA piece of step s + 2.  One barrier per step, in
-    // the middle (before tile 5): it publishes step s + 1 (every wave has waited for its own pieces) and tells that
-    // every wave is past step s - 1, whose slot the DMA of step s + 2 overwrites.  Fragments are read TWO tiles ahead
+    // wave's issue port for 8 of its 32 cycles) -- the two fragment reads of the tile two ahead, and in tiles 5..9 one
+    // LDS-DMA piece of step s + 6.  No vector arithmetic is left in the loop: the B operand was split once, in LayerNorm 1.  One barrier per step, in
+    // the middle (before tile 5): it publishes step s + 1 (every wave has waited for its own pieces of it with a COUNTED
+    // vmcnt that leaves the four younger steps in flight) and tells that every wave is past step s - 1, whose slot the
+    // DMA of step s + 6 overwrites.  Fragments are read TWO tiles ahead
     // (tiles 0, 1 of step s + 1 during tiles 8, 9 of step s, after that barrier), so a read has six MFMAs to land.
 #define SB __builtin_amdgcn_sched_barrier(0)
-    uint32_t cb[2][4], nb[2][4];                           // B fragments (h, m) of this step and the next
-#pragma unroll
-    for (int q = 0; q < 4; ++q) split2(acc1[0][2 * q], acc1[0][2 * q + 1], cb[0][q], cb[1][q]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // steps 0 and 1 (this wave's pieces)
+    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");      // steps 0 and 1 (this wave's pieces); 2..5 may still fly
     __builtin_amdgcn_s_barrier();
     // A fragments (h, m) of three consecutive tiles: the current one, the next, and the one being read (two ahead);
     // rotated by renaming at the end of every tile (the loops are fully unrolled: no moves)
@@ -274,14 +305,23 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
     SB;
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-        const uint4 vh = make_uint4(cb[0][0], cb[0][1], cb[0][2], cb[0][3]), vm = make_uint4(cb[1][0], cb[1][1], cb[1][2], cb[1][3]);
+        const uint4 vh = make_uint4(hb[s][0], hb[s][1], hb[s][2], hb[s][3]), vm = make_uint4(mb[s][0], mb[s][1], mb[s][2], mb[s][3]);
         const uint4 *slot = ring + (s % RING) * CHUNK_U4 + lane;
         const uint4 *nslot = ring + ((s + 1) % RING) * CHUNK_U4 + lane;
 #pragma unroll
         for (int u = 0; u < T2; ++u) {
             if (u == T2 / 2) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // step s + 1 must have landed; the steps issued after it (up to four) may still be in flight
+                switch (STEPS - 2 - s < 4 ? STEPS - 2 - s : 4) {
+                    case 4: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                }
+#ifndef TT_DBG_NOBAR
                 __builtin_amdgcn_s_barrier();
+#endif
                 SB;
             }
             const bool more = u + 2 < T2 || s + 1 < STEPS;                    // is there a tile two ahead to prefetch
@@ -293,17 +333,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
             if (more) c2m = nx[64];
             SB;
             acc2[u] = mfma_f16(c0h, vh, acc2[u]); SB;
-            if (u < 4 && s + 1 < STEPS)
-                split2(acc1[(s + 1) >> 1][8 * ((s + 1) & 1) + 2 * u], acc1[(s + 1) >> 1][8 * ((s + 1) & 1) + 2 * u + 1],
-                       nb[0][u], nb[1][u]);
-            if (u >= 5 && s + 2 < STEPS) chunk_issue_piece(s + 2, u - 5);
+#ifndef TT_DBG_NODMA
+            if (u >= 5 && s + RING - 1 < STEPS) chunk_issue_piece(s + RING - 1, u - 5);
+#endif
             SB;
             c0h = c1h; c0m = c1m; c1h = c2h; c1m = c2m;
         }
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cb[p][q] = nb[p][q];
     }
 #undef SB
 
@@ -362,6 +397,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
 #ifdef TT_STAMPS
 int split_debug_stamps(unsigned long long *out16) {
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_nstamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -3;
+}
+int split_debug_block_stamps(unsigned long long *out, int nblocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bstamps), sizeof(unsigned long long) * 8 * (nblocks < 4096 ? nblocks : 4096)) == hipSuccess ? 0 : -3;
 }
 #endif
 
