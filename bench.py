@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--step-graph", type=int, default=4, help="ddpg workload: whole vector steps per captured hipGraph "
                     "(0: only learn() is captured)")
     ap.add_argument("--torch-learn", action="store_true", help="learn() through torch autograd instead of the fused HIP kernels")
+    ap.add_argument("--serial", action="store_true", help="ddpg workload: the reference's strict order (policy, env step, then "
+                    "learn() on a window that includes the new step) instead of the pipelined one")
     ap.add_argument("--graph-steps", type=int, default=50, help="env workload: vector steps per captured hipGraph")
     return ap.parse_args()
 
@@ -302,7 +304,8 @@ def main():
         from ddpg_trucktrailer_amd.rollout import DDPGRollout
         loop = DDPGRollout(env, batch_size=args.batch, replay_slots=args.replay_slots, seed=27 + rank,
                            world_size=world, use_graph=not args.no_graph, fused_learn=not args.torch_learn,
-                           graph_steps=args.step_graph, updates_per_step=args.updates_per_step)
+                           graph_steps=args.step_graph, updates_per_step=args.updates_per_step,
+                           pipeline=False if args.serial else None)
         loop.prepare()       # one-off work (4 untimed vector steps + graph capture) before warm-up and the timed region
         ddpg_loop = loop
         run = loop.run       # every step a hipGraph replay (G-step graphs where aligned, single-step graphs elsewhere)
@@ -314,8 +317,11 @@ def main():
                       "three hipGraph segments per step with the two RCCL gradient all-reduces between them")
         else:
             launch = "eager, learn() as a hipGraph" if loop.use_graph else "eager"
+        order = ("pipelined: learn() of vector step t (batch from the steps before t) runs beside the policy + env launches of "
+                 "step t on a second graph branch; the policy acts with the weights learn() of step t-1 left"
+                 if loop.pipeline else "serial: policy, env step, then learn() on a window that includes the new step")
         extra = {"batch": args.batch, "updates_per_step": args.updates_per_step,
-                 "replay_capacity": args.replay_slots * n, "launch": launch}
+                 "replay_capacity": args.replay_slots * n, "launch": launch, "order": order}
 
     def sync_all():
         torch.cuda.synchronize()

@@ -35,7 +35,7 @@ class TTInfo(C.Structure):
 class TTMlpWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "w3", "b3", "wa", "ba")] + \
                [("in_dim", C.c_int32), ("fc1_dims", C.c_int32), ("fc2_dims", C.c_int32), ("reserved_", C.c_int32),
-                ("split_ws", C.c_void_p)]
+                ("split_ws", C.c_void_p), ("ws_packed", C.c_int32), ("max_workgroups", C.c_int32)]
 
 
 class TTMlpSaved(C.Structure):
@@ -98,10 +98,11 @@ _SIGNATURES = {
     "tt_env_profile": (C.c_int, [_P, _I]),
     "tt_env_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "tt_mlp_split_ws_bytes": (C.c_uint64, []),
+    "tt_mlp_split_pack": (C.c_int, [C.POINTER(TTMlpWeights), _I, _P, _P, _P]),
     "tt_actor_forward": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_actor_act": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P, _U64, _U64, _P, C.c_float, C.c_float, C.c_float,
                                _P, _P, _P, _P]),
-    "tt_ring_sample": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _U64, C.POINTER(TTSideBuffer), _P, _P, _P, _P, _P, _P, _P]),
+    "tt_ring_sample": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _U64, _I, C.POINTER(TTSideBuffer), _P, _P, _P, _P, _P, _P, _P]),
     "tt_critic_forward": (C.c_int, [_I, _P, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_mlp_forward_save": (C.c_int, [_I, _I, _P, _P, C.POINTER(TTMlpWeights), _P, C.POINTER(TTMlpSaved), _P, _P]),
     "tt_mlp_forward_multi": (C.c_int, [_I, _I, C.POINTER(TTFwdJob), _P]),

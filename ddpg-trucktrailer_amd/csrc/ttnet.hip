@@ -249,14 +249,15 @@ __global__ __launch_bounds__(64) void k_ring_sample(const int batch, const int n
                                                     const long long *__restrict__ k_dev, const float *__restrict__ obs,
                                                     const float *__restrict__ act, const float *__restrict__ rew,
                                                     const uint8_t *__restrict__ done, const unsigned long long seed,
-                                                    const SideBuf side, float *__restrict__ s_out,
+                                                    const int reserve, const SideBuf side, float *__restrict__ s_out,
                                                     float *__restrict__ a_out, float *__restrict__ r_out,
                                                     float *__restrict__ s2_out, uint8_t *__restrict__ d_out,
                                                     int *__restrict__ idx_out) {
     const int b = blockIdx.x;
     if (b >= batch) return;
     const long long k = *k_dev;                       // vector steps completed; transitions k-avail .. k-1 are intact
-    const long long avail = k < slots - 1 ? k : slots - 1;
+    const long long cap = slots - 1 - reserve;       // reserve: slots a concurrent env step is overwriting (pipelined loop)
+    const long long avail = k < cap ? k : cap;
     uint32_t r[4];
     philox4x32((uint32_t)b, (uint32_t)k, (uint32_t)(k >> 32), 0x5A3Du, (uint32_t)seed, (uint32_t)(seed >> 32), r);
     const int lane = threadIdx.x;
@@ -316,7 +317,8 @@ template <bool CRITIC>
 int launch(int n, const float *obs, const float *action, const tt_mlp_weights *w, float *out, const ActArgs &act,
            hipStream_t stream) {
     if (use_split(n, w)) {
-        const int rc = split_pack(w, CRITIC, w->split_ws, stream);
+        // ws_packed: the caller keeps the image current itself (tt_mlp_split_pack after every weight update)
+        const int rc = w->ws_packed ? TT_OK : split_pack(w, CRITIC, w->split_ws, nullptr, stream);
         return rc != TT_OK ? rc : split_forward(CRITIC, n, obs, action, w, out, act, stream);
     }
     static bool attr2[64] = {};     // per device
@@ -344,6 +346,11 @@ int tt_debug_bstamps(unsigned long long *out, int nblocks) { return ttnet::split
 
 uint64_t tt_mlp_split_ws_bytes(void) { return (uint64_t)split_ws_bytes(); }
 
+int tt_mlp_split_pack(const tt_mlp_weights *w, int critic, void *ws, int64_t *bump, tt_stream_t stream) {
+    if (!ws || !check_ptrs(w, critic != 0)) return TT_EINVAL;
+    return split_pack(w, critic != 0, ws, reinterpret_cast<long long *>(bump), stream);
+}
+
 
 int tt_actor_forward(int n, const float *obs, const tt_mlp_weights *w, float *mu_out, tt_stream_t stream) {
     if (n < 0 || !obs || !mu_out || !check_ptrs(w, false)) return TT_EINVAL;
@@ -366,9 +373,9 @@ int tt_actor_act(int n, const float *obs, const tt_mlp_weights *w, float *ou_sta
 }
 
 int tt_ring_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const float *obs, const float *act,
-                   const float *rew, const uint8_t *done, uint64_t seed, const tt_side_buffer *side, float *s_out,
+                   const float *rew, const uint8_t *done, uint64_t seed, int reserve, const tt_side_buffer *side, float *s_out,
                    float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out, tt_stream_t stream) {
-    if (batch < 0 || n_envs <= 0 || slots < 3 || !k_dev || !obs || !act || !rew || !done || !s_out || !a_out || !r_out ||
+    if (batch < 0 || n_envs <= 0 || reserve < 0 || slots < 3 + reserve || !k_dev || !obs || !act || !rew || !done || !s_out || !a_out || !r_out ||
         !s2_out || !d_out)
         return TT_EINVAL;
     SideBuf sb{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
@@ -378,7 +385,7 @@ int tt_ring_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const
     }
     if (batch == 0) return TT_OK;
     hipLaunchKernelGGL(k_ring_sample, dim3(batch), dim3(64), 0, stream, batch, n_envs, slots,
-                       reinterpret_cast<const long long *>(k_dev), obs, act, rew, done, seed, sb, s_out, a_out, r_out,
+                       reinterpret_cast<const long long *>(k_dev), obs, act, rew, done, seed, reserve, sb, s_out, a_out, r_out,
                        s2_out, d_out, idx_out);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }

@@ -79,7 +79,7 @@ inline Weights to_weights(const tt_mlp_weights *w) {
 
 // csrc/ttnet_split.hip
 size_t split_ws_bytes();
-int split_pack(const tt_mlp_weights *w, bool critic, void *ws, hipStream_t stream);
+int split_pack(const tt_mlp_weights *w, bool critic, void *ws, long long *bump, hipStream_t stream);
 int split_forward(bool critic, int n, const float *obs, const float *action, const tt_mlp_weights *w, float *out,
                   const ActArgs &act, hipStream_t stream);
 #ifdef TT_STAMPS

@@ -101,9 +101,11 @@ __device__ __forceinline__ f32x16 mfma_f16(const uint4 a, const uint4 b, const f
 //     in which a 32x32 accumulator tile presents its rows when it is used as the other operand; plane 0 = h, 1 = m;
 //   fc1 [400,23] + bias -> w1p[s][t][plane][lane]: neuron 32t + r at inputs 16 s + 8 h + j (natural order; input 23
 //     carries the bias, the observation operand carries a 1 there);
-//   vec: g1*SX | be1*SX [2][416], b2 | g2 | be2 | w3 | wa | ba [6][320], zero beyond the real neurons.
-__global__ __launch_bounds__(256) void k_split_pack(const Weights W, const bool critic, unsigned char *__restrict__ ws) {
+//   vec: g1*SX | be1*SX [2][416], b2 | g2 | be2 | w3 | wa | ba [6][320], zero beyond the real neurons; then b3.
+__global__ __launch_bounds__(256) void k_split_pack(const Weights W, const bool critic, unsigned char *__restrict__ ws,
+                                                    long long *__restrict__ bump) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (bump && idx == 0) *bump += 1;      // optional step counter of a pipelined loop (read by LATER launches only)
     constexpr int N2 = STEPS * T2 * 64, N1 = S1 * T1 * 64;
     if (idx < N2 + N1) {
         const bool l2 = idx < N2;
@@ -146,6 +148,8 @@ __global__ __launch_bounds__(256) void k_split_pack(const Weights W, const bool 
             const float *src[6] = {W.b2, W.g2, W.be2, W.w3, W.wa, W.ba};
             if (a < 4 || critic) v = src[a][m];
         }
+    } else if (i == VEC_FLOATS) {
+        v = W.b3[0];                       // the head's bias travels with the image: the forward reads NOTHING else of the net
     }
     vec[i] = v;
 }
@@ -153,7 +157,7 @@ constexpr int PACK_THREADS = (STEPS * T2 + S1 * T1) * 64 + VEC_BYTES / 4;
 
 template <bool CRITIC>
 __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *__restrict__ obs,
-                                                      const float *__restrict__ action, const float *__restrict__ b3p,
+                                                      const float *__restrict__ action,
                                                       const unsigned char *__restrict__ ws, float *__restrict__ out,
                                                       const ActArgs act) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -164,7 +168,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int row = blockIdx.x * ROWS + wave * WROWS + r;                     // this lane's env (lanes r and r+32 share it)
+    // Persistent over 128-env tiles: workgroup b takes tiles b, b + gridDim.x, ...  (a capped grid leaves CUs to a learn()
+    // chain running beside the policy on another stream; packed fc1 shares LDS with the fc2 ring and is re-staged per tile)
+    const int ntiles = (n + ROWS - 1) / ROWS;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool first_tile = tile == (int)blockIdx.x;
+    const int row = tile * ROWS + wave * WROWS + r;                           // this lane's env (lanes r and r+32 share it)
 
     // LDS is filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = one 1 KB piece per wave-instruction, no
     // staging registers).  The statements are inline asm, so hipcc neither counts them nor drains them at a barrier:
@@ -198,10 +207,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
 #pragma unroll
     for (int i = 0; i < W1_PIECES / 4; ++i)
         dma_piece(ws + WS_W1 + (wave * (W1_PIECES / 4) + i) * 1024, lds_base + W1_OFF + (wave * (W1_PIECES / 4) + i) * 1024);
+    if (first_tile) {                                                         // the per-neuron vectors stay for all tiles
 #pragma unroll
-    for (int i = 0; i < VEC_PIECES / 4; ++i)
-        dma_piece(ws + WS_VEC + (wave * (VEC_PIECES / 4) + i) * 1024,
-                  lds_base + RING_BYTES + (wave * (VEC_PIECES / 4) + i) * 1024);
+        for (int i = 0; i < VEC_PIECES / 4; ++i)
+            dma_piece(ws + WS_VEC + (wave * (VEC_PIECES / 4) + i) * 1024,
+                      lds_base + RING_BYTES + (wave * (VEC_PIECES / 4) + i) * 1024);
+    }
 #pragma unroll
     for (int i = 0; i < 10; ++i) chunk_issue_piece(i / 5, i % 5);
 #pragma unroll
@@ -387,9 +398,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
             dot = fmaf(fmaxf(y0, 0.f), w3.x, dot); dot = fmaf(fmaxf(y1, 0.f), w3.y, dot);      // w3 = 0 on padding
             dot = fmaf(fmaxf(y2, 0.f), w3.z, dot); dot = fmaf(fmaxf(y3, 0.f), w3.w, dot);
         }
-    const float v = dot + __shfl_xor(dot, 32) + b3p[0];
+    const float v = dot + __shfl_xor(dot, 32) + p1_s[VEC_FLOATS];
     if (h == 0 && row < n) finish_row<CRITIC>(row, v, out, act);
     NSTAMP(5);
+    __builtin_amdgcn_s_barrier();          // every wave is done with the ring before the next tile's DMA overwrites it
+    }   // tiles
 }
 
 }  // namespace
@@ -405,9 +418,9 @@ int split_debug_block_stamps(unsigned long long *out, int nblocks) {
 
 size_t split_ws_bytes() { return (size_t)WS_BYTES; }
 
-int split_pack(const tt_mlp_weights *w, bool critic, void *ws, hipStream_t stream) {
+int split_pack(const tt_mlp_weights *w, bool critic, void *ws, long long *bump, hipStream_t stream) {
     hipLaunchKernelGGL(k_split_pack, dim3((PACK_THREADS + 255) / 256), dim3(256), 0, stream, to_weights(w), critic,
-                       reinterpret_cast<unsigned char *>(ws));
+                       reinterpret_cast<unsigned char *>(ws), bump);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 
@@ -423,8 +436,12 @@ static int launch_split(int n, const float *obs, const float *action, const tt_m
             return TT_EHIP;
         attr[dev] = true;
     }
-    hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3((n + ROWS - 1) / ROWS), dim3(256), LDS_BYTES, stream, n, obs, action,
-                       w->b3, reinterpret_cast<const unsigned char *>(w->split_ws), out, act);
+    // one workgroup per CU is resident (LDS): a grid of at most 256 covers the chip and takes the tiles in rounds by itself;
+    // max_workgroups caps it lower for callers that run something else beside this kernel
+    const int ntiles = (n + ROWS - 1) / ROWS;
+    const int cap = w->max_workgroups > 0 ? w->max_workgroups : 256;
+    hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(ntiles < cap ? ntiles : cap), dim3(256), LDS_BYTES, stream, n, obs, action,
+                       reinterpret_cast<const unsigned char *>(w->split_ws), out, act);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 

@@ -22,14 +22,8 @@ def supported(net):
             and tuple(net.fc2.weight.shape) == (300, 400) and net.bn1.eps == 1e-5 and net.bn2.eps == 1e-5)
 
 
-def weights_of(net):
-    """TTMlpWeights over the module's parameter storages (valid while the parameters are updated in place)."""
-    cached = getattr(net, "_tt_weights", None)
-    key = tuple(p.data_ptr() for p in net.parameters())
-    if cached is not None and cached[0] == key:
-        return cached[1]
+def _fill_weights(net, w):
     head = net.mu if hasattr(net, "mu") else net.q
-    w = L.TTMlpWeights()
     for name, t in (("w1", net.fc1.weight), ("b1", net.fc1.bias), ("g1", net.bn1.weight), ("be1", net.bn1.bias),
                     ("w2", net.fc2.weight), ("b2", net.fc2.bias), ("g2", net.bn2.weight), ("be2", net.bn2.bias),
                     ("w3", head.weight), ("b3", head.bias)):
@@ -38,12 +32,48 @@ def weights_of(net):
     if hasattr(net, "action_value"):
         w.wa, w.ba = net.action_value.weight.data_ptr(), net.action_value.bias.data_ptr()
     w.in_dim, w.fc1_dims, w.fc2_dims = 23, 400, 300
+    return w
+
+
+def weights_of(net):
+    """TTMlpWeights over the module's parameter storages (valid while the parameters are updated in place)."""
+    cached = getattr(net, "_tt_weights", None)
+    key = tuple(p.data_ptr() for p in net.parameters())
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    w = _fill_weights(net, L.TTMlpWeights())
     # workspace of the split-f16 kernel (csrc/ttnet_split.hip), re-packed from the weights by every call that uses it; one per
     # module, so two streams never share one (the learner's side stream runs other modules)
     net._tt_split_ws = torch.empty(int(L.load().tt_mlp_split_ws_bytes()), dtype=torch.uint8, device=net.fc2.weight.device)
     w.split_ws = net._tt_split_ws.data_ptr()
     net._tt_weights = (key, w)
     return w
+
+
+def packed_weights_of(net, index, max_workgroups=None):
+    """TTMlpWeights whose split-kernel image is kept current BY THE CALLER (pack()): one of two private workspaces per
+    module (index 0 / 1), so a loop can fill the image for the next step while a forward still reads this step's.
+    Forwards through it never re-pack and read nothing of the live parameters."""
+    cache = net.__dict__.setdefault("_tt_packed", {})
+    key = tuple(p.data_ptr() for p in net.parameters())
+    hit = cache.get(index)
+    if hit is None or hit[0] != key:
+        w = _fill_weights(net, L.TTMlpWeights())
+        ws = torch.empty(int(L.load().tt_mlp_split_ws_bytes()), dtype=torch.uint8, device=net.fc2.weight.device)
+        w.split_ws, w.ws_packed = ws.data_ptr(), 1
+        hit = cache[index] = (key, w, ws)
+    if max_workgroups is not None:
+        hit[1].max_workgroups = int(max_workgroups)
+    return hit[1]
+
+
+def pack(net, index, bump=None):
+    """Write the split kernel's image of `net`'s CURRENT weights into its workspace `index` (tt_mlp_split_pack);
+    bump: device int64 scalar incremented by the launch (a pipelined loop's step counter) or None."""
+    w = packed_weights_of(net, index)
+    dev = net.fc2.weight.device
+    L.check(L.load().tt_mlp_split_pack(C.byref(w), 1 if hasattr(net, "action_value") else 0, C.c_void_p(w.split_ws),
+                                       _ptr(bump), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 
 
 @contextlib.contextmanager
@@ -79,10 +109,11 @@ def critic_forward(net, obs, action, out=None):
 
 
 def actor_act(net, obs, ou_state, act_raw, act_scaled, seed, step=0, step_dev=None, done_prev=None, mu_out=None,
-              theta=0.2, sigma=0.15, dt=1e-2, high=math.pi / 4):
-    """choose_action + OU noise + clip*high for all rows in one launch (see include/ttenv.h: tt_actor_act)."""
+              theta=0.2, sigma=0.15, dt=1e-2, high=math.pi / 4, weights=None):
+    """choose_action + OU noise + clip*high for all rows in one launch (see include/ttenv.h: tt_actor_act).
+    weights: a packed_weights_of() struct (the caller keeps its image current); default: re-pack on every call."""
     n = obs.shape[0]
-    L.check(L.load().tt_actor_act(n, _ptr(obs), C.byref(weights_of(net)), _ptr(ou_state), _ptr(done_prev),
+    L.check(L.load().tt_actor_act(n, _ptr(obs), C.byref(weights if weights is not None else weights_of(net)), _ptr(ou_state), _ptr(done_prev),
                                   int(seed) & (2 ** 64 - 1), int(step), _ptr(step_dev), float(theta * dt),
                                   float(sigma * math.sqrt(dt)), float(high), _ptr(mu_out), _ptr(act_raw),
                                   _ptr(act_scaled), _stream(obs)))

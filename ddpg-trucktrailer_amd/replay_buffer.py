@@ -153,9 +153,11 @@ class TrajectoryRing:
         self.k = int(sd["k"])               # the counters come back whether or not the contents did
         self.k_dev.fill_(self.k)
 
-    def sample_fused(self, batch_size, seed=0, return_index=False, done_as_bool=True):
+    def sample_fused(self, batch_size, seed=0, return_index=False, done_as_bool=True, k_dev=None, reserve=0):
         """sample() as ONE HIP launch (tt_ring_sample): Philox indices keyed by (seed, k_dev) + gather.
-        done_as_bool=False returns the raw uint8 flags (no conversion launch; what the fused learner takes)."""
+        done_as_bool=False returns the raw uint8 flags (no conversion launch; what the fused learner takes).
+        k_dev / reserve: another device step counter and the number of newest slots to keep out of the window (a pipelined
+        loop samples BESIDE the env step of the same vector step: include/ttenv.h, tt_ring_sample)."""
         import ctypes as C
         from ddpg_trucktrailer_amd import _lib as L
         if getattr(self, "_bufs", None) is None or self._bufs[0].shape[0] != batch_size:
@@ -167,8 +169,9 @@ class TrajectoryRing:
         s, a, r, s2, dn, idx = self._bufs
         p = lambda t: C.c_void_p(t.data_ptr())
         side = self._side_struct()
-        L.check(L.load().tt_ring_sample(batch_size, self.n, self.slots, p(self.k_dev), p(self.obs), p(self.act), p(self.rew),
-                                        p(self.done), int(seed) & (2 ** 64 - 1), C.byref(side) if side is not None else None,
+        L.check(L.load().tt_ring_sample(batch_size, self.n, self.slots, p(self.k_dev if k_dev is None else k_dev), p(self.obs),
+                                        p(self.act), p(self.rew), p(self.done), int(seed) & (2 ** 64 - 1), int(reserve),
+                                        C.byref(side) if side is not None else None,
                                         p(s), p(a), p(r), p(s2), p(dn), p(idx),
                                         C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         out = (s, a, r, s2, dn.bool() if done_as_bool else dn)

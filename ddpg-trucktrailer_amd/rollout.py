@@ -14,7 +14,18 @@ position are.  step() is the same vector step launched eagerly, with learn() alo
 them give the same bits.
 
 Data-parallel ranks (one process per GPU): a step is three graph segments with the two gradient all-reduces of
-DDPG_agent.py:95-104 between them, launched eagerly on RCCL (the collectives are not captured)."""
+DDPG_agent.py:95-104 between them, launched eagerly on RCCL (the collectives are not captured).
+
+pipeline=True (the default on a GPU with the fused learner): learn() of vector step t runs BESIDE the policy and env
+launches of step t, on a second stream / graph branch, and the two meet at the end of the step.  What this needs:
+  * learn() of step t samples transitions of steps < t (the reference's, and pipeline=False's, window also holds step t:
+    a one-slot difference, stated like the other choices of the vector loop);
+  * the policy reads a packed IMAGE of the actor (csrc/ttnet_split.hip) that learn() of step t-1 wrote at its end, one of
+    two buffers used in turn, never the live weights that learn() of step t is updating -- the policy of step t still acts
+    with the weights after learn() of step t-1, exactly as in the serial order;
+  * the policy kernel's grid is capped (policy_workgroups) so that learn()'s launches always find free CUs.
+No launch of one branch reads what a launch of the other writes within a step, so graphs, eager launches and a resumed
+run still agree bit for bit."""
 import math
 import os
 
@@ -37,7 +48,7 @@ _MAX_GRAPH_SLOTS = 1024               # whole-step graphs exist per ring positio
 class DDPGRollout:
     def __init__(self, env, batch_size=256, replay_slots=64, seed=27, alpha=1e-4, beta=1e-3, tau=1e-3, gamma=0.99,
                  fc1_dims=400, fc2_dims=300, world_size=1, use_graph=True, agent=None, fused_learn=True, graph_steps=4,
-                 updates_per_step=1, data_parallel=None):
+                 updates_per_step=1, data_parallel=None, pipeline=None, policy_workgroups=192):
         """updates_per_step: learn() calls per vector step (the reference does one per ENV step, trainv2.py:520-528; one
         per vector step is 1/N of that -- the knob moves the data/update ratio back towards the reference's).
         data_parallel: None = (world_size > 1); True forces the data-parallel launch structure with the process group's
@@ -83,6 +94,17 @@ class DDPGRollout:
             self.learner.grad_sync_critic = self.learner.grad_sync_actor = lambda: None
         self.graph = None
         self._learn_side, self._learn_warm = None, 0
+        # pipelined order (module docstring): needs the fused learner, the fused policy kernel and a ring with an even
+        # number of slots (the policy's two weight images alternate with the ring position)
+        can_pipe = self.learner is not None and self.fused_act and self.device.type == "cuda" and replay_slots % 2 == 0 \
+            and replay_slots >= 4 and self.ring._env_counts
+        self.pipeline = can_pipe if pipeline is None else (bool(pipeline) and can_pipe)
+        self.policy_workgroups = int(policy_workgroups)
+        self.k_pipe_dev = torch.zeros((), dtype=torch.int64, device=self.device)   # steps completed before the running one
+        self._pipe_side = None
+        if self.pipeline:
+            self._pipe_side = torch.cuda.Stream(device=self.device)
+            fused.pack(self.agent.actor, 0)                   # the image the policy of step 0 reads
         self.vector_steps = 0
         # whole-step graphs: the ring slots a step touches depend on k mod slots only, so a graph of G steps captured at
         # ring position c*G is valid whenever k = c*G (mod slots): slots/G graphs cover the cycle, and one single-step
@@ -98,13 +120,16 @@ class DDPGRollout:
 
     # -------------------------------------------------------------- acting
     @torch.no_grad()
-    def act(self, obs, act_out, done_prev=None):
+    def act(self, obs, act_out, done_prev=None, k=None):
         if self.fused_act:     # actor forward + OU noise + clip*high in ONE launch (tt_actor_act)
+            w = None
+            if self.pipeline:  # the image learn() of the previous step left for this ring position
+                w = fused.packed_weights_of(self.agent.actor, (self.ring.k if k is None else k) & 1, self.policy_workgroups)
             if self.ring._env_counts:      # noise keyed by the DEVICE step counter: the launch is graph-replayable
                 return fused.actor_act(self.agent.actor, obs, self.noise.x, act_out, self.scaled, seed=self.seed,
-                                       step=0, step_dev=self.ring.k_dev, done_prev=done_prev, high=self.high)
+                                       step=0, step_dev=self.ring.k_dev, done_prev=done_prev, high=self.high, weights=w)
             return fused.actor_act(self.agent.actor, obs, self.noise.x, act_out, self.scaled, seed=self.seed,
-                                   step=self.vector_steps, done_prev=done_prev, high=self.high)
+                                   step=self.vector_steps, done_prev=done_prev, high=self.high, weights=w)
         if done_prev is not None:
             self.noise.reset(done_prev)
         mu = self.agent.actor(obs).view(-1)
@@ -116,6 +141,8 @@ class DDPGRollout:
     def _sample(self, u):
         key = (self.seed + u * _SEED_STRIDE) & (2 ** 64 - 1)
         if self.device.type == "cuda":
+            if self.pipeline:      # beside the env step of the same vector step: its slot is not part of the window
+                return self.ring.sample_fused(self.batch_size, seed=key, done_as_bool=False, k_dev=self.k_pipe_dev, reserve=1)
             return self.ring.sample_fused(self.batch_size, seed=key, done_as_bool=self.learner is None)
         return self.ring.sample(self.batch_size)
 
@@ -164,13 +191,35 @@ class DDPGRollout:
         t, t1 = ring.slot(k), ring.slot(k + 1)
         # the noise of an env whose episode ended at the previous step restarts at 0 (trainv2.py:492)
         done_prev = ring.done[ring.slot(k - 1)] if k > 0 else None
-        scaled = self.act(ring.obs[t], ring.act[t], done_prev)
+        scaled = self.act(ring.obs[t], ring.act[t], done_prev, k=k)
         self.env.step(scaled, auto_reset=True, obs_out=ring.obs[t1], reward_out=ring.rew[t], done_out=ring.done[t])
 
+    def _pipelined(self, k, learn_fn):
+        """Vector step k in the pipelined order, on the current stream and the side stream: learn() and the pack of the
+        next step's policy image on the side, policy + env step on the current one, joined at the end.  Works the same
+        under capture (two branches of the graph) and eagerly (two streams)."""
+        cur, side = torch.cuda.current_stream(self.device), self._pipe_side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            learn_fn()
+        self._act_and_step(k)
+        cur.wait_stream(side)
+
+    def _learn_and_pack(self, k, learn):
+        if learn:
+            self._learn_all()
+        fused.pack(self.agent.actor, (k + 1) & 1, bump=self.k_pipe_dev)      # image for step k + 1; k_pipe -> k + 1
+
     def step(self):
-        self._act_and_step(self.ring.k)
-        self.ring.advance()
-        self.learn()
+        k = self.ring.k
+        if self.pipeline:
+            self._check_epoch()
+            self._pipelined(k, lambda: self._learn_and_pack(k, k >= 2))
+            self.ring.advance()
+        else:
+            self._act_and_step(k)
+            self.ring.advance()
+            self.learn()
         self.vector_steps += 1
 
     # -------------------------------------------------------------- many vector steps
@@ -199,7 +248,14 @@ class DDPGRollout:
         return g
 
     def _capture_body(self, k):
-        self._act_and_step(self.ring.slots + k)      # + slots: any k > 0 with this ring position
+        kk = self.ring.slots + k                     # + slots: any k > 0 with this ring position (and parity: slots is even)
+        if self.pipeline:
+            if self.dp:                              # up to the critic's gradient beside the policy; the rest in _dp_step
+                self._pipelined(kk, lambda: self.learner.phase_a(*self._sample(0), fuse_adam=False))
+            else:
+                self._pipelined(kk, lambda: self._learn_and_pack(kk, True))
+            return
+        self._act_and_step(kk)
         if self.dp:
             s, a, r, s2, d = self._sample(0)
             self.learner.phase_a(s, a, r, s2, d, fuse_adam=False)
@@ -226,6 +282,9 @@ class DDPGRollout:
             pieces = {"b": lambda: self.learner.phase_b(s, separate_adam=True), "c": self.learner.phase_c}
             for u in range(1, self.updates_per_step):      # the further updates of a step: sample + up to the critic's gradient
                 pieces[("a", u)] = (lambda u=u: self.learner.phase_a(*self._sample(u), fuse_adam=False))
+            if self.pipeline:                               # the pack that ends a step's learn(), per image
+                for par in (0, 1):
+                    pieces[("pack", par)] = (lambda par=par: fused.pack(self.agent.actor, par, bump=self.k_pipe_dev))
             for name, fn in pieces.items():
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side, capture_error_mode=_CAPTURE_MODE):
@@ -244,6 +303,8 @@ class DDPGRollout:
             self.dp_graphs["b"].replay()
             self.learner.grad_sync_actor()
             self.dp_graphs["c"].replay()
+        if self.pipeline:
+            self.dp_graphs[("pack", (self.ring.k + 1) & 1)].replay()
 
     def _try_capture(self):
         try:
@@ -326,6 +387,9 @@ class DDPGRollout:
         self.noise.x.copy_(sd["ou"].to(self.noise.x.device))
         if sd.get("env") is not None:
             self.env.load_state_dict(sd["env"])                       # bumps env.graph_epoch: graphs are re-captured
+        self.k_pipe_dev.fill_(self.ring.k)
+        if self.pipeline:
+            fused.pack(self.agent.actor, self.ring.k & 1)             # the image the next policy launch reads
         if int(sd["seed"]) != int(self.seed):
             self.invalidate_graphs()                                  # the Philox keys are kernel arguments
         self.seed = int(sd["seed"])

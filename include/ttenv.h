@@ -194,9 +194,9 @@ int tt_random_actions(int n, uint64_t seed, uint64_t step, float *out, tt_stream
  * eps 1e-5) at f32 accuracy.  Pointers are torch parameter storages (row-major [out,in]):
  *   w1 [400,23] b1 g1 be1 [400] = fc1, bn1;  w2 [300,400] b2 g2 be2 [300] = fc2, bn2;  w3 [300] b3 [1] = mu / q;
  *   wa [300] ba [300] = action_value (critic only).  Other shapes return TT_EINVAL (callers fall back to torch).
- * Two kernels serve a forward: the exact-f32 MFMA kernel (csrc/ttnet.hip), and for n >= 1024 rows the split-bf16
- * kernel (csrc/ttnet_split.hip: every f32 operand is the exact sum of three bf16 pieces, six bf16 MFMAs with f32
- * accumulation per product block, error below the f32 product's own rounding) when split_ws is set: a caller-owned
+ * Two kernels serve a forward: the exact-f32 MFMA kernel (csrc/ttnet.hip), and for n >= 1024 rows the split-f16
+ * kernel (csrc/ttnet_split.hip: every f32 operand is, to within its own rounding, the sum of two round-to-nearest f16
+ * pieces; three f16 MFMAs with f32 accumulation per product block) when split_ws is set: a caller-owned
  * device workspace of tt_mlp_split_ws_bytes() bytes, one per network and per stream that may run it concurrently,
  * into which each call re-packs fc2 before it runs (never stale; the contents are private to the library).
  * split_ws = NULL always selects the exact-f32 kernel.  Structs of gradients (tt_mlp_backward) ignore it. */
@@ -204,8 +204,16 @@ typedef struct tt_mlp_weights {
     const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *w3, *b3, *wa, *ba;
     int32_t in_dim, fc1_dims, fc2_dims, reserved_;
     void *split_ws;
+    int32_t ws_packed;      /* != 0: split_ws already holds the image of these weights (tt_mlp_split_pack): forwards do not
+                               re-pack and read nothing but the image, so the weights may be updated beside them */
+    int32_t max_workgroups; /* > 0: the split kernel's grid is capped at this many workgroups (one per CU is resident), leaving
+                               the other CUs to launches on other streams; 0 = one per CU */
 } tt_mlp_weights;
 uint64_t tt_mlp_split_ws_bytes(void);
+/* Write the split kernel's image of `w` (fc2 and fc1 as pre-split f16 fragments, per-neuron vectors, head bias) into ws
+ * (tt_mlp_split_ws_bytes() bytes).  bump (may be NULL): a device int64 that this launch increments by one -- the step
+ * counter of a pipelined loop whose learn() chain ends with this pack. */
+int tt_mlp_split_pack(const tt_mlp_weights *w, int critic, void *ws, int64_t *bump, tt_stream_t stream);
 
 /* ActorNetwork.forward (DDPG/networks.py:138-147) for n rows: mu_out [n] = tanh(mu(...)). */
 int tt_actor_forward(int n, const float *obs /*[n,23]*/, const tt_mlp_weights *w, float *mu_out, tt_stream_t stream);
@@ -224,6 +232,9 @@ int tt_actor_act(int n, const float *obs, const tt_mlp_weights *w, float *ou_sta
  * obs[t+1][e], done[t][e]); *k_dev = vector steps completed, read on the device, so a captured hipGraph draws new
  * indices at every replay.  Outputs: s_out, s2_out [batch,23], a_out, r_out [batch] f32, d_out [batch] u8,
  * idx_out [batch,2] i32 (slot, env) or NULL.
+ * reserve: 0, or the number of most recent ring slots a CONCURRENT env step may be writing (a pipelined loop samples
+ * beside the step launch: then *k_dev counts the steps completed before that launch and reserve = 1 keeps the draw off the
+ * observation row it overwrites); the window is min(*k_dev, slots - 1 - reserve) steps.
  * side (may be NULL): stand-alone transitions that are not part of any env's trajectory -- the expert tuples
  * `(obs, action / radians(45), reward, obs_next, done)` that trainv2.py:457-466 re-inserts with agent.remember
  * (produced by exp_gen.py:77-110).  They take part in the same uniform draw: with `count` side transitions and R
@@ -235,7 +246,7 @@ typedef struct tt_side_buffer {
     int32_t count, reserved_;
 } tt_side_buffer;
 int tt_ring_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const float *obs, const float *act,
-                   const float *rew, const uint8_t *done, uint64_t seed, const tt_side_buffer *side, float *s_out,
+                   const float *rew, const uint8_t *done, uint64_t seed, int reserve, const tt_side_buffer *side, float *s_out,
                    float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out, tt_stream_t stream);
 
 /* CriticNetwork.forward (DDPG/networks.py:55-68) for n rows: q_out [n]. */

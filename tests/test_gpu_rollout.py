@@ -51,7 +51,7 @@ def test_vector_loop_ring_and_learn(gpu_device, use_graph):
     n = 4096
     env = TruckTrailerVecEnv(n)
     env.reset(seed=27)
-    loop = DDPGRollout(env, batch_size=256, replay_slots=8, seed=27, use_graph=use_graph)
+    loop = DDPGRollout(env, batch_size=256, replay_slots=8, seed=27, use_graph=use_graph, pipeline=False)
     first_obs = loop.ring.obs[0].clone()
     assert torch.equal(first_obs, env.observe(out=torch.empty_like(first_obs)))
     # detach(): a clone that keeps its grad_fn pins the parameter's AccumulateGrad node to THIS stream, and a
@@ -185,7 +185,7 @@ def test_whole_step_graphs_match_eager_steps(gpu_device):
     for net in ("actor", "critic", "target_actor", "target_critic"):
         for x, y in zip(getattr(a.agent, net).state_dict().values(), getattr(b.agent, net).state_dict().values()):
             assert torch.equal(x, y), net
-    assert int(a.learner.step_dev.item()) == int(b.learner.step_dev.item()) >= k - 1    # learn() from the 2nd step on
+    assert int(a.learner.step_dev.item()) == int(b.learner.step_dev.item()) >= k - 2    # learn() from the 2nd / 3rd step on
     for lp in loops:
         lp.env.close()
 
@@ -245,7 +245,7 @@ def test_updates_per_step(gpu_device):
     for _ in range(14):
         b.step()
     torch.cuda.synchronize()
-    assert int(a.learner.step_dev.item()) == int(b.learner.step_dev.item()) == 3 * 13      # learn() from the 2nd step on
+    assert int(a.learner.step_dev.item()) == int(b.learner.step_dev.item()) == 3 * 12      # pipelined order: learn() from the 3rd step on
     assert torch.equal(_loop_flat(a), _loop_flat(b))
     s0 = a._sample(0)[0].clone(); s1 = a._sample(1)[0].clone()
     assert not torch.equal(s0, s1), "the updates of one vector step must draw different batches"
@@ -335,9 +335,55 @@ def test_whole_config3_loop_at_bench_size(gpu_device):
         torch.cuda.synchronize()
         flat = _loop_flat(loop)
         assert torch.isfinite(flat).all() and not torch.equal(flat, w0)
-        assert torch.isfinite(loop.ring.rew[:12]).all() and int(loop.learner.step_dev.item()) == 11
+        assert torch.isfinite(loop.ring.rew[:12]).all() and int(loop.learner.step_dev.item()) == 10
         flats.append((flat.clone(), loop.ring.obs[:13].clone(), loop.env.state.clone()))
         env.close()
         del loop
     for x, y in zip(*flats):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("pipeline", [True, False])
+def test_pipelined_and_serial_orders(gpu_device, pipeline):
+    """Both orders of a vector step: graphs == eager bit for bit, exactly one learn() per step from the third step on,
+    and in the pipelined order the batch of step t holds transitions of steps < t only while the policy of step t acts
+    with the weights learn() of step t-1 left (its packed image)."""
+    import torch
+    from ddpg_trucktrailer_amd import fused
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    n, k = 2048, 23
+    loops = []
+    for graph_steps in (4, 0):
+        env = TruckTrailerVecEnv(n)
+        env.reset(seed=5)
+        loops.append(DDPGRollout(env, batch_size=256, replay_slots=8, seed=5, graph_steps=graph_steps, pipeline=pipeline))
+    a, b = loops
+    assert a.pipeline == b.pipeline == pipeline
+    a.run(k)
+    for _ in range(k):
+        b.step()
+    torch.cuda.synchronize()
+    assert torch.equal(_loop_flat(a), _loop_flat(b))
+    for name in ("obs", "act", "rew", "done"):
+        assert torch.equal(getattr(a.ring, name), getattr(b.ring, name)), name
+    assert torch.equal(a.noise.x, b.noise.x) and torch.equal(a.env.state, b.env.state)
+    want = k - 2 if pipeline else k - 1               # pipelined: learn() in steps 2..k-1; serial: after steps 1..k-1
+    assert int(a.learner.step_dev.item()) == int(b.learner.step_dev.item()) == want
+    if pipeline:
+        assert int(a.k_pipe_dev.item()) == int(b.k_pipe_dev.item()) == k
+        # the window of the next batch: steps k-6 .. k-1 (slots - 2 = 6 of them), never the slot the env step is writing
+        _, _, _, _, _, idx = a.ring.sample_fused(4096, seed=1, return_index=True, k_dev=a.k_pipe_dev, reserve=1)
+        t = idx[:, 0].long()
+        assert set(t.unique().tolist()) == {(k - 1 - j) % 8 for j in range(6)}
+        # the policy's image for the next step is the pack of the CURRENT actor
+        w = fused.packed_weights_of(a.agent.actor, k & 1)
+        obs = a.ring.obs[a.ring.slot()].clone()
+        mu_img = torch.empty(n, device=gpu_device)
+        import ctypes as C
+        from ddpg_trucktrailer_amd import _lib as L
+        L.check(L.load().tt_actor_forward(n, C.c_void_p(obs.data_ptr()), C.byref(w), C.c_void_p(mu_img.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        assert (mu_img.view(-1, 1) - fused.actor_forward(a.agent.actor, obs)).abs().max().item() == 0.0
+    for lp in loops:
+        lp.env.close()
