@@ -301,7 +301,7 @@ int check_ptrs(const tt_mlp_weights *w, bool critic) {
 }
 
 
-// which kernel serves a forward of n rows: the split-bf16 kernel needs the caller's workspace and pays a weight-pack
+// which kernel serves a forward of n rows: the split-f16 kernel needs the caller's workspace and pays a weight-pack
 // launch per call, so it takes over from 1024 rows; TT_MLP_KERNEL=f32 / split forces one (A/B measurements, tests)
 bool use_split(int n, const tt_mlp_weights *w) {
     static int forced = -1;
@@ -309,7 +309,9 @@ bool use_split(int n, const tt_mlp_weights *w) {
         const char *e = getenv("TT_MLP_KERNEL");
         forced = !e ? 0 : (e[0] == 'f' ? 1 : (e[0] == 's' ? 2 : 0));
     }
-    if (!w->split_ws || forced == 1) return false;
+    if (!w->split_ws) return false;
+    if (w->ws_packed) return true;      // the caller keeps an image BECAUSE the live weights may be changing: never read them
+    if (forced == 1) return false;
     return forced == 2 || n >= 1024;
 }
 

@@ -160,7 +160,11 @@ class DDPGRollout:
     def learn(self):
         if self.ring.k < 2:
             return
-        if not self.use_graph or self.dp:      # (collectives are not captured)
+        # Only the fused learner's launches are captured.  The torch-autograd learner stays eager: its backward runs on
+        # the autograd engine's thread and synchronises with whatever stream each parameter's gradient accumulator was
+        # first used on -- a graph node kept alive elsewhere (a clone that carries its grad_fn, made on another stream) pulls
+        # that stream into the capture, and HIP's EndCapture then takes the PROCESS down (no exception to fall back from).
+        if not self.use_graph or self.dp or self.learner is None:      # (collectives are not captured either)
             return self._learn_all()
         self._check_epoch()
         if self.graph is None:
@@ -307,6 +311,13 @@ class DDPGRollout:
             self.dp_graphs[("pack", (self.ring.k + 1) & 1)].replay()
 
     def _try_capture(self):
+        import gc
+        # No garbage collection while a capture is open: a collected hipGraph, stream, event or env handle of some EARLIER
+        # object runs HIP calls in its destructor that are illegal during capture (torch aborts the process).  Collect
+        # first, then keep the collector off until the last graph is captured.
+        gc.collect()
+        was_on = gc.isenabled()
+        gc.disable()
         try:
             self._capture_step_graphs()
             return True
@@ -316,6 +327,9 @@ class DDPGRollout:
             self.invalidate_graphs()
             self.graph_steps = 0
             return False
+        finally:
+            if was_on:
+                gc.enable()
 
     def prepare(self):
         """Everything one-off that run() would otherwise do lazily inside its first calls (a few eager vector steps that

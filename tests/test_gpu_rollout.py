@@ -253,11 +253,12 @@ def test_updates_per_step(gpu_device):
         lp.env.close()
 
 
-def test_torch_learn_path_captured_equals_eager(gpu_device):
-    """DDPGRollout(fused_learn=False): learn() through torch autograd, captured into a hipGraph.  A clone of a parameter
-    that still carries its grad_fn, made on ANOTHER stream, keeps that parameter's AccumulateGrad node pinned there --
-    the situation in which a captured backward() used to fork the capture and crash HIP's EndCapture; learn_batch takes
-    its gradients from torch.autograd.grad, which does not go through those nodes."""
+def test_torch_learn_path_is_never_captured(gpu_device):
+    """DDPGRollout(fused_learn=False, use_graph=True): learn() through torch autograd.  A clone of a parameter that still
+    carries its grad_fn, made on ANOTHER stream, keeps that parameter's gradient accumulator pinned there; a captured
+    backward then pulls that stream into the capture and HIP's EndCapture crashes the process (seen in round 1 and again
+    with torch.autograd.grad).  The loop therefore never captures this learner: use_graph only covers the fused one, and
+    the two settings give the same weights."""
     import torch
     from ddpg_trucktrailer_amd.rollout import DDPGRollout
     from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
@@ -266,7 +267,7 @@ def test_torch_learn_path_captured_equals_eager(gpu_device):
         env = TruckTrailerVecEnv(256)
         env.reset(seed=4)
         loop = DDPGRollout(env, batch_size=64, replay_slots=8, seed=4, use_graph=use_graph, fused_learn=False)
-        assert loop.learner is None
+        assert loop.learner is None and not loop.pipeline
         loops.append(loop)
     a, b = loops
     keep = [p.clone() for p in a.agent.critic.parameters()] + [p.clone() for p in a.agent.actor.parameters()]
@@ -274,10 +275,8 @@ def test_torch_learn_path_captured_equals_eager(gpu_device):
     for _ in range(9):
         a.step(); b.step()
     torch.cuda.synchronize()
-    assert a.graph is not None and b.graph is None
-    for x, y in zip(_loop_flat(a).split(4096), _loop_flat(b).split(4096)):
-        assert torch.allclose(x, y, rtol=1e-5, atol=1e-7)
-    assert torch.isfinite(_loop_flat(a)).all()
+    assert a.graph is None and b.graph is None
+    assert torch.equal(_loop_flat(a), _loop_flat(b)) and torch.isfinite(_loop_flat(a)).all()
     del keep
     for lp in loops:
         lp.env.close()
