@@ -51,7 +51,7 @@ class TTFwdJob(C.Structure):
 class TTTdInput(C.Structure):
     _fields_ = [("z_state", C.c_void_p), ("mu_target", C.c_void_p), ("target_critic", C.POINTER(TTMlpWeights)),
                 ("reward", C.c_void_p), ("done", C.c_void_p), ("gamma", C.c_float), ("reserved_", C.c_float),
-                ("y_out", C.c_void_p), ("q_out", C.c_void_p), ("step_dev", C.c_void_p)]
+                ("y_out", C.c_void_p), ("q_out", C.c_void_p), ("step_dev", C.c_void_p), ("window_dev", C.c_void_p)]
 
 
 class TTDqdaInput(C.Structure):

@@ -396,7 +396,7 @@ struct TdIn {
     const float *__restrict__ wa, *__restrict__ ba, *__restrict__ w3, *__restrict__ b3;     // the target critic's
     float gamma;
     float *__restrict__ y_out, *__restrict__ q_out;
-    long long *__restrict__ step_dev;
+    long long *__restrict__ step_dev, *__restrict__ window_dev;
 };
 
 template <bool CRITIC>
@@ -446,7 +446,10 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
             zt[rr][i] = (real && with_td) ? td.z_state[q] : 0.f;
         }
     }
-    if (with_td && blockIdx.x == 0 && tid == 0 && td.step_dev) *td.step_dev += 1;
+    if (with_td && blockIdx.x == 0 && tid == 0) {
+        if (td.step_dev) *td.step_dev += 1;
+        if (td.window_dev) *td.window_dev += 1;      // a pipelined loop's sampling window moves on (read by LATER launches only)
+    }
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const int lr = wave * RPW + rr, row = row0 + lr;
@@ -1041,7 +1044,8 @@ static int backward_impl(int n, int critic, int mode, float scale, const float *
             !tdi->y_out)
             return TT_EINVAL;
         td = TdIn{tdi->z_state, tdi->mu_target, tdi->reward, tdi->done, tw->wa, tw->ba, tw->w3, tw->b3, tdi->gamma,
-                  tdi->y_out, tdi->q_out, reinterpret_cast<long long *>(tdi->step_dev)};
+                  tdi->y_out, tdi->q_out, reinterpret_cast<long long *>(tdi->step_dev),
+                  reinterpret_cast<long long *>(tdi->window_dev)};
     }
     if (!saved->xh1 || !saved->h1 || !saved->xh2 || !saved->h2 || !saved->rstd1 || !saved->rstd2 || !ws->dpre || !ws->dz ||
         !ws->dx2 || !ws->dy1 || !ws->dx1)

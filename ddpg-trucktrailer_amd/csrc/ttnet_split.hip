@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_split_pack(const Weights W, const bool 
 constexpr int PACK_THREADS = (STEPS * T2 + S1 * T1) * 64 + VEC_BYTES / 4;
 
 template <bool CRITIC>
-__global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *__restrict__ obs,
+__global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int tile0, const float *__restrict__ obs,
                                                       const float *__restrict__ action,
                                                       const unsigned char *__restrict__ ws, float *__restrict__ out,
                                                       const ActArgs act) {
@@ -168,11 +168,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    // Persistent over 128-env tiles: workgroup b takes tiles b, b + gridDim.x, ...  (a capped grid leaves CUs to a learn()
-    // chain running beside the policy on another stream; packed fc1 shares LDS with the fc2 ring and is re-staged per tile)
-    const int ntiles = (n + ROWS - 1) / ROWS;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const bool first_tile = tile == (int)blockIdx.x;
+    // One 128-env tile per workgroup (a loop over tiles inside the kernel costs ~400 spilled registers: the compiler hoists
+    // the tile-invariant DMA addresses); a caller that wants CUs left free launches the tiles in several grids (tile0).
+    const int tile = tile0 + blockIdx.x;
+    const unsigned char *wsl = ws;
     const int row = tile * ROWS + wave * WROWS + r;                           // this lane's env (lanes r and r+32 share it)
 
     // LDS is filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = one 1 KB piece per wave-instruction, no
@@ -185,8 +184,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(lane_off), "s"(src), "s"(dst) : "memory");
     };
+    const unsigned char *wsl_cur = wsl;
     auto chunk_issue_piece = [&](const int s, const int i) {                  // piece i (0..4) of this wave's share of step s
-        dma_piece(ws + WS_W2 + (size_t)s * CHUNK_BYTES + wave * 5120 + i * 1024,
+        dma_piece(wsl_cur + WS_W2 + (size_t)s * CHUNK_BYTES + wave * 5120 + i * 1024,
                   lds_base + (s % RING) * CHUNK_BYTES + wave * 5120 + i * 1024);
     };
 
@@ -206,13 +206,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
         }
 #pragma unroll
     for (int i = 0; i < W1_PIECES / 4; ++i)
-        dma_piece(ws + WS_W1 + (wave * (W1_PIECES / 4) + i) * 1024, lds_base + W1_OFF + (wave * (W1_PIECES / 4) + i) * 1024);
-    if (first_tile) {                                                         // the per-neuron vectors stay for all tiles
+        dma_piece(wsl + WS_W1 + (wave * (W1_PIECES / 4) + i) * 1024, lds_base + W1_OFF + (wave * (W1_PIECES / 4) + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < VEC_PIECES / 4; ++i)
-            dma_piece(ws + WS_VEC + (wave * (VEC_PIECES / 4) + i) * 1024,
-                      lds_base + RING_BYTES + (wave * (VEC_PIECES / 4) + i) * 1024);
-    }
+    for (int i = 0; i < VEC_PIECES / 4; ++i)
+        dma_piece(wsl + WS_VEC + (wave * (VEC_PIECES / 4) + i) * 1024,
+                  lds_base + RING_BYTES + (wave * (VEC_PIECES / 4) + i) * 1024);
 #pragma unroll
     for (int i = 0; i < 10; ++i) chunk_issue_piece(i / 5, i % 5);
 #pragma unroll
@@ -401,8 +399,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const float *
     const float v = dot + __shfl_xor(dot, 32) + p1_s[VEC_FLOATS];
     if (h == 0 && row < n) finish_row<CRITIC>(row, v, out, act);
     NSTAMP(5);
-    __builtin_amdgcn_s_barrier();          // every wave is done with the ring before the next tile's DMA overwrites it
-    }   // tiles
 }
 
 }  // namespace
@@ -436,12 +432,17 @@ static int launch_split(int n, const float *obs, const float *action, const tt_m
             return TT_EHIP;
         attr[dev] = true;
     }
-    // one workgroup per CU is resident (LDS): a grid of at most 256 covers the chip and takes the tiles in rounds by itself;
-    // max_workgroups caps it lower for callers that run something else beside this kernel
+    // one workgroup per CU is resident (LDS).  max_workgroups > 0: the tiles go out in consecutive grids of at most that
+    // many workgroups, so that never more than that many CUs are busy with this forward (the rest stay free for launches on
+    // other streams); 0: one grid, the hardware takes the tiles in rounds
     const int ntiles = (n + ROWS - 1) / ROWS;
-    const int cap = w->max_workgroups > 0 ? w->max_workgroups : 256;
-    hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(ntiles < cap ? ntiles : cap), dim3(256), LDS_BYTES, stream, n, obs, action,
-                       reinterpret_cast<const unsigned char *>(w->split_ws), out, act);
+    const int limit = w->max_workgroups > 0 ? w->max_workgroups : ntiles;
+    const int grids = (ntiles + limit - 1) / limit, cap = (ntiles + grids - 1) / grids;      // equal shares: 512 tiles, limit 192 -> 171, 171, 170
+    for (int t0 = 0; t0 < ntiles; t0 += cap) {
+        const int g = ntiles - t0 < cap ? ntiles - t0 : cap;
+        hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(g), dim3(256), LDS_BYTES, stream, n, t0, obs, action,
+                           reinterpret_cast<const unsigned char *>(w->split_ws), out, act);
+    }
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 

@@ -133,7 +133,7 @@ class FusedLearner:
 
     # learn() in the three pieces the two gradient all-reduces cut it into (each piece is pure kernel launches on the
     # current stream, so a data-parallel loop can capture each as a hipGraph and keep only the collectives eager)
-    def phase_a(self, states, actions, rewards, states_, done_u8, fuse_adam):
+    def phase_a(self, states, actions, rewards, states_, done_u8, fuse_adam, window_dev=None):
         """Forwards, TD target, critic backward (+ the critic's Adam/soft update in the same launch when fuse_adam)."""
         ag, B = self.agent, self.B
         # DDPG_agent.py:85-93 and :87, :101.  Only the target critic's LAST step needs the target actor's action (it enters
@@ -159,7 +159,8 @@ class FusedLearner:
         td = L.TTTdInput(z_state=self.z_t.data_ptr(), mu_target=self.mu_t.data_ptr(),
                          target_critic=C.pointer(fused.weights_of(ag.target_critic)), reward=rewards.data_ptr(),
                          done=done_u8.data_ptr(), gamma=float(ag.gamma), y_out=self.y.data_ptr(),
-                         q_out=self.q_t.data_ptr(), step_dev=self.step_dev.data_ptr())
+                         q_out=self.q_t.data_ptr(), step_dev=self.step_dev.data_ptr(),
+                         window_dev=window_dev.data_ptr() if window_dev is not None else None)
         if fuse_adam:
             self._bwd_adam(self.critic, self.hyp_critic, ag.tau, 1, 2.0 / B, states, actions, self.q, td=td)
         else:
@@ -181,11 +182,12 @@ class FusedLearner:
     def phase_c(self):
         self._adam(self.actor, self.hyp_actor, self.agent.tau)
 
-    def learn_batch(self, states, actions, rewards, states_, done_u8):
-        """states, states_ [B,23] f32; actions [B,1] f32; rewards [B] f32; done_u8 [B] uint8 -- all contiguous."""
+    def learn_batch(self, states, actions, rewards, states_, done_u8, window_dev=None):
+        """states, states_ [B,23] f32; actions [B,1] f32; rewards [B] f32; done_u8 [B] uint8 -- all contiguous.
+        window_dev: device int64 advanced by the critic's backward launch (a pipelined loop's sampling window)."""
         assert states.shape[0] == self.B and done_u8.dtype == torch.uint8
         dp = self.grad_sync_critic is not None
-        self.phase_a(states, actions, rewards, states_, done_u8, fuse_adam=not dp)
+        self.phase_a(states, actions, rewards, states_, done_u8, fuse_adam=not dp, window_dev=window_dev)
         if dp:
             self.grad_sync_critic()
         self.phase_b(states, separate_adam=dp)

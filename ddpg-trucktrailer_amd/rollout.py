@@ -20,9 +20,9 @@ pipeline=True (the default on a GPU with the fused learner): learn() of vector s
 launches of step t, on a second stream / graph branch, and the two meet at the end of the step.  What this needs:
   * learn() of step t samples transitions of steps < t (the reference's, and pipeline=False's, window also holds step t:
     a one-slot difference, stated like the other choices of the vector loop);
-  * the policy reads a packed IMAGE of the actor (csrc/ttnet_split.hip) that learn() of step t-1 wrote at its end, one of
-    two buffers used in turn, never the live weights that learn() of step t is updating -- the policy of step t still acts
-    with the weights after learn() of step t-1, exactly as in the serial order;
+  * the policy reads a packed IMAGE of the actor (csrc/ttnet_split.hip) made at the start of step t, before the two
+    branches part, from the weights learn() of step t-1 left -- never the live weights learn() of step t is updating -- so
+    the policy of step t acts with the weights after learn() of step t-1, exactly as in the serial order;
   * the policy kernel's grid is capped (policy_workgroups) so that learn()'s launches always find free CUs.
 No launch of one branch reads what a launch of the other writes within a step, so graphs, eager launches and a resumed
 run still agree bit for bit."""
@@ -94,17 +94,15 @@ class DDPGRollout:
             self.learner.grad_sync_critic = self.learner.grad_sync_actor = lambda: None
         self.graph = None
         self._learn_side, self._learn_warm = None, 0
-        # pipelined order (module docstring): needs the fused learner, the fused policy kernel and a ring with an even
-        # number of slots (the policy's two weight images alternate with the ring position)
-        can_pipe = self.learner is not None and self.fused_act and self.device.type == "cuda" and replay_slots % 2 == 0 \
-            and replay_slots >= 4 and self.ring._env_counts
+        # pipelined order (module docstring): needs the fused learner and the fused policy kernel
+        can_pipe = self.learner is not None and self.fused_act and self.device.type == "cuda" and replay_slots >= 4 \
+            and self.ring._env_counts
         self.pipeline = can_pipe if pipeline is None else (bool(pipeline) and can_pipe)
-        self.policy_workgroups = int(policy_workgroups)
+        self.policy_workgroups = int(os.environ.get("TT_POLICY_WG", policy_workgroups))     # (env: A/B measurements)
         self.k_pipe_dev = torch.zeros((), dtype=torch.int64, device=self.device)   # steps completed before the running one
         self._pipe_side = None
         if self.pipeline:
             self._pipe_side = torch.cuda.Stream(device=self.device)
-            fused.pack(self.agent.actor, 0)                   # the image the policy of step 0 reads
         self.vector_steps = 0
         # whole-step graphs: the ring slots a step touches depend on k mod slots only, so a graph of G steps captured at
         # ring position c*G is valid whenever k = c*G (mod slots): slots/G graphs cover the cycle, and one single-step
@@ -123,8 +121,8 @@ class DDPGRollout:
     def act(self, obs, act_out, done_prev=None, k=None):
         if self.fused_act:     # actor forward + OU noise + clip*high in ONE launch (tt_actor_act)
             w = None
-            if self.pipeline:  # the image learn() of the previous step left for this ring position
-                w = fused.packed_weights_of(self.agent.actor, (self.ring.k if k is None else k) & 1, self.policy_workgroups)
+            if self.pipeline:  # the image packed at the start of this step, never the live weights learn() is updating
+                w = fused.packed_weights_of(self.agent.actor, 0, self.policy_workgroups)
             if self.ring._env_counts:      # noise keyed by the DEVICE step counter: the launch is graph-replayable
                 return fused.actor_act(self.agent.actor, obs, self.noise.x, act_out, self.scaled, seed=self.seed,
                                        step=0, step_dev=self.ring.k_dev, done_prev=done_prev, high=self.high, weights=w)
@@ -149,7 +147,9 @@ class DDPGRollout:
     def _learn_once(self, u=0):
         s, a, r, s2, d = self._sample(u)
         if self.learner is not None:
-            self.learner.learn_batch(s, a, r, s2, d)                      # raw uint8 done flags of the sample
+            # (pipelined order) the last update of a vector step moves the sampling window on
+            last = self.pipeline and u == self.updates_per_step - 1
+            self.learner.learn_batch(s, a, r, s2, d, window_dev=self.k_pipe_dev if last else None)   # raw uint8 done flags
         else:
             self.agent.learn_batch(s, a, r, s2, d)
 
@@ -198,27 +198,33 @@ class DDPGRollout:
         scaled = self.act(ring.obs[t], ring.act[t], done_prev, k=k)
         self.env.step(scaled, auto_reset=True, obs_out=ring.obs[t1], reward_out=ring.rew[t], done_out=ring.done[t])
 
-    def _pipelined(self, k, learn_fn):
-        """Vector step k in the pipelined order, on the current stream and the side stream: learn() and the pack of the
-        next step's policy image on the side, policy + env step on the current one, joined at the end.  Works the same
-        under capture (two branches of the graph) and eagerly (two streams)."""
+    def _pipelined(self, k, learn, dp_capture=False):
+        """Vector step k in the pipelined order, on the current stream and the side stream:
+            current:  pack the policy's image from the actor as learn() of step k-1 left it; then, beside each other,
+            side:     learn(), whose last update moves the sampling window on      | current:  policy, env step
+        joined at the end.  The same code runs under capture (two branches of one graph) and eagerly (two streams).  The
+        pack sits BEFORE the fork: with it on the policy branch and an event into the middle of learn() (which would take
+        it off learn()'s path) ROCm's graph executor runs the two branches one after the other (tools/graph_probe2.py).
+        dp_capture: only learn()'s first segment (up to the critic's gradient) goes beside the policy; _dp_step does the rest."""
         cur, side = torch.cuda.current_stream(self.device), self._pipe_side
+        fused.pack(self.agent.actor, 0)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            learn_fn()
+            if dp_capture:
+                self.learner.phase_a(*self._sample(0), fuse_adam=False,
+                                     window_dev=self.k_pipe_dev if self.updates_per_step == 1 else None)
+            elif learn:
+                self._learn_all()
+            else:
+                self.k_pipe_dev.add_(1)                     # no learn() yet: the window still moves with the steps
         self._act_and_step(k)
         cur.wait_stream(side)
-
-    def _learn_and_pack(self, k, learn):
-        if learn:
-            self._learn_all()
-        fused.pack(self.agent.actor, (k + 1) & 1, bump=self.k_pipe_dev)      # image for step k + 1; k_pipe -> k + 1
 
     def step(self):
         k = self.ring.k
         if self.pipeline:
             self._check_epoch()
-            self._pipelined(k, lambda: self._learn_and_pack(k, k >= 2))
+            self._pipelined(k, k >= 2)
             self.ring.advance()
         else:
             self._act_and_step(k)
@@ -254,10 +260,8 @@ class DDPGRollout:
     def _capture_body(self, k):
         kk = self.ring.slots + k                     # + slots: any k > 0 with this ring position (and parity: slots is even)
         if self.pipeline:
-            if self.dp:                              # up to the critic's gradient beside the policy; the rest in _dp_step
-                self._pipelined(kk, lambda: self.learner.phase_a(*self._sample(0), fuse_adam=False))
-            else:
-                self._pipelined(kk, lambda: self._learn_and_pack(kk, True))
+            # (data-parallel: up to the critic's gradient beside the policy; the rest in _dp_step)
+            self._pipelined(kk, True, dp_capture=self.dp)
             return
         self._act_and_step(kk)
         if self.dp:
@@ -285,10 +289,9 @@ class DDPGRollout:
             self.dp_graphs = {}
             pieces = {"b": lambda: self.learner.phase_b(s, separate_adam=True), "c": self.learner.phase_c}
             for u in range(1, self.updates_per_step):      # the further updates of a step: sample + up to the critic's gradient
-                pieces[("a", u)] = (lambda u=u: self.learner.phase_a(*self._sample(u), fuse_adam=False))
-            if self.pipeline:                               # the pack that ends a step's learn(), per image
-                for par in (0, 1):
-                    pieces[("pack", par)] = (lambda par=par: fused.pack(self.agent.actor, par, bump=self.k_pipe_dev))
+                last = self.pipeline and u == self.updates_per_step - 1
+                pieces[("a", u)] = (lambda u=u, last=last: self.learner.phase_a(
+                    *self._sample(u), fuse_adam=False, window_dev=self.k_pipe_dev if last else None))
             for name, fn in pieces.items():
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side, capture_error_mode=_CAPTURE_MODE):
@@ -307,8 +310,6 @@ class DDPGRollout:
             self.dp_graphs["b"].replay()
             self.learner.grad_sync_actor()
             self.dp_graphs["c"].replay()
-        if self.pipeline:
-            self.dp_graphs[("pack", (self.ring.k + 1) & 1)].replay()
 
     def _try_capture(self):
         import gc
@@ -402,8 +403,6 @@ class DDPGRollout:
         if sd.get("env") is not None:
             self.env.load_state_dict(sd["env"])                       # bumps env.graph_epoch: graphs are re-captured
         self.k_pipe_dev.fill_(self.ring.k)
-        if self.pipeline:
-            fused.pack(self.agent.actor, self.ring.k & 1)             # the image the next policy launch reads
         if int(sd["seed"]) != int(self.seed):
             self.invalidate_graphs()                                  # the Philox keys are kernel arguments
         self.seed = int(sd["seed"])

@@ -206,8 +206,8 @@ typedef struct tt_mlp_weights {
     void *split_ws;
     int32_t ws_packed;      /* != 0: split_ws already holds the image of these weights (tt_mlp_split_pack): forwards do not
                                re-pack and read nothing but the image, so the weights may be updated beside them */
-    int32_t max_workgroups; /* > 0: the split kernel's grid is capped at this many workgroups (one per CU is resident), leaving
-                               the other CUs to launches on other streams; 0 = one per CU */
+    int32_t max_workgroups; /* > 0: the split kernel's workgroups (one per CU is resident) go out in consecutive grids of at most
+                               this many, leaving the other CUs to launches on other streams; 0 = one grid */
 } tt_mlp_weights;
 uint64_t tt_mlp_split_ws_bytes(void);
 /* Write the split kernel's image of `w` (fc2 and fc1 as pre-split f16 fragments, per-neuron vectors, head bias) into ws
@@ -312,6 +312,8 @@ typedef struct tt_td_input {
     float gamma, reserved_;
     float *y_out, *q_out;
     int64_t *step_dev;
+    int64_t *window_dev;   /* optional: a second device counter advanced by 1 -- the sampling-window counter of a pipelined
+                              loop (tt_ring_sample's k_dev), moved on by the last learn() of a vector step */
 } tt_td_input;
 /* dq (optional, actor with mode 2 only; aux may then be NULL): the critic forward that produces aux = dQ/da done in the
  * actor's per-row backward launch -- Q(s, out) on `critic` for the same rows (DDPG_agent.py:101-102), q_out [n] and

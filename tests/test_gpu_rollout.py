@@ -375,14 +375,17 @@ def test_pipelined_and_serial_orders(gpu_device, pipeline):
         _, _, _, _, _, idx = a.ring.sample_fused(4096, seed=1, return_index=True, k_dev=a.k_pipe_dev, reserve=1)
         t = idx[:, 0].long()
         assert set(t.unique().tolist()) == {(k - 1 - j) % 8 for j in range(6)}
-        # the policy's image for the next step is the pack of the CURRENT actor
-        w = fused.packed_weights_of(a.agent.actor, k & 1)
+        # the policy acted with an image of the actor as learn() of the previous step left it: run one more step and compare
+        # the stored action means with the pre-step actor on the observations the policy saw
         obs = a.ring.obs[a.ring.slot()].clone()
-        mu_img = torch.empty(n, device=gpu_device)
-        import ctypes as C
-        from ddpg_trucktrailer_amd import _lib as L
-        L.check(L.load().tt_actor_forward(n, C.c_void_p(obs.data_ptr()), C.byref(w), C.c_void_p(mu_img.data_ptr()),
-                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        assert (mu_img.view(-1, 1) - fused.actor_forward(a.agent.actor, obs)).abs().max().item() == 0.0
+        ou_before = a.noise.x.clone()
+        done_prev = a.ring.done[a.ring.slot(a.ring.k - 1)].bool()
+        mu_before = fused.actor_forward(a.agent.actor, obs).view(-1).clone()
+        a.run(1)
+        torch.cuda.synchronize()
+        stored = a.ring.act[a.ring.slot(a.ring.k - 1)]
+        mu_used = stored - a.noise.x                                   # stored action = mu + the step's OU state
+        assert (mu_used - mu_before).abs().max().item() <= 1e-6
+        assert not torch.equal(fused.actor_forward(a.agent.actor, obs).view(-1), mu_before)   # learn() did move the actor meanwhile
     for lp in loops:
         lp.env.close()

@@ -140,8 +140,8 @@ def test_simv1_at_bench_size(gpu_device):
         # done <=> a cause of the simv1 mask; the two unmasked causes alone never end an episode
         assert torch.equal(d, (fl & L.default_params(1).term_mask) != 0)
         masked_only += int(((fl & 0x30) != 0).logical_and((fl & 0x0F) == 0).sum())
-        # positions / 40 are not clipped (simv2.py:103-110): the step that leaves the map reports slightly more than 1
-        assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and (obs.abs() <= 1.25).all()
+        # (finished envs keep moving here -- auto_reset is off -- so positions / 40 leave [-1, 1]; everything else is bounded)
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
         assert (obs[:, [2, 3, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 20, 21, 22]].abs() <= 1.0 + 1e-6).all()
         o_obs, o_rew, o_done, o_info = ora.step(a[:m].cpu().numpy(), nthreads=8)
         k = alive
