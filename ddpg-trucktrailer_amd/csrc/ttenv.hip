@@ -639,15 +639,26 @@ __global__ __launch_bounds__(BLOCK) void k_step(const KParams P, const int n, co
     if (valid) {
         Env e;
         load_env<PER_ENV>(P, b, i, e);
-        float a;
+        float a = 0.f;
+        if (!RANDOM_POLICY) a = action[i];
+        // A lone wave per SIMD hides no latency: every load of the step is requested HERE, in one burst (one trip to
+        // L2 / the Infinity Cache instead of the four or five the scheduler otherwise spreads through the arithmetic by
+        // sinking each load next to its first use)
+        __builtin_amdgcn_sched_barrier(0);
         if (RANDOM_POLICY) {
             a = random_action(policy_seed, (uint32_t)i, pk_steps(e.pk), b.episodes[i]);
             if (action_out) action_out[i] = a;
-        } else {
-            a = action[i];
         }
         StepOut o;
+#ifdef TT_DBG_STEP_MEM_ONLY      // diagnostic build (wrong results): the step's memory traffic without its arithmetic
+        o = StepOut{};
+        o.total = e.psi1 + a; o.done = false;
+        e.psi1 += 1e-9; e.psi2 += e.x1 * 1e-12; e.d3 = e.d2; e.d2 = e.d1; e.d1 = e.prev; e.cum += e.closest * 1e-12;
+#pragma unroll
+        for (int j = 0; j < OBS; ++j) of[j] = (float)(e.x2 + j);
+#else
         step_env(P, e, a, of, o);
+#endif
         reward[i] = (float)o.total;
         done[i] = o.done ? 1 : 0;
         if (INFO) write_info(info, (size_t)n, i, e, o);
