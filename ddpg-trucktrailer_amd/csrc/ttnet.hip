@@ -233,65 +233,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_forward_v2(const int n, const fl
     }
 }
 
-// Uniform sampling WITH replacement from the trajectory ring (replay_buffer.py:23-34 draws np.random.choice(max_mem,
-// batch)): one workgroup per sampled transition gathers s, a, r, s', done into the batch buffers.  The ring's step
-// counter is read from device memory so that a captured hipGraph of learn() samples fresh indices every replay
-// (the Philox counter includes it).  An optional side buffer of stand-alone transitions (expert tuples re-inserted the
-// way trainv2.py:457-466 `remember`s them) is part of the same uniform draw: with M side transitions and R intact ring
-// transitions each of the M + R is picked with probability 1/(M + R).
-struct SideBuf {
-    const float *obs, *act, *rew, *obs2;
-    const uint8_t *done;
-    int count;
-};
-
-__global__ __launch_bounds__(64) void k_ring_sample(const int batch, const int n_envs, const int slots,
-                                                    const long long *__restrict__ k_dev, const float *__restrict__ obs,
-                                                    const float *__restrict__ act, const float *__restrict__ rew,
-                                                    const uint8_t *__restrict__ done, const unsigned long long seed,
-                                                    const int reserve, const SideBuf side, float *__restrict__ s_out,
-                                                    float *__restrict__ a_out, float *__restrict__ r_out,
-                                                    float *__restrict__ s2_out, uint8_t *__restrict__ d_out,
-                                                    int *__restrict__ idx_out) {
-    const int b = blockIdx.x;
-    if (b >= batch) return;
-    const long long k = *k_dev;                       // vector steps completed; transitions k-avail .. k-1 are intact
-    const long long cap = slots - 1 - reserve;       // reserve: slots a concurrent env step is overwriting (pipelined loop)
-    const long long avail = k < cap ? k : cap;
-    uint32_t r[4];
-    philox4x32((uint32_t)b, (uint32_t)k, (uint32_t)(k >> 32), 0x5A3Du, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    const int lane = threadIdx.x;
-    if (side.count > 0) {
-        const unsigned long long in_ring = (unsigned long long)avail * (unsigned long long)n_envs;
-        const unsigned long long u = ((unsigned long long)r[2] << 32) | r[3];
-        if (__umul64hi(u, in_ring + (unsigned long long)side.count) < (unsigned long long)side.count) {
-            const int j = (int)(((unsigned long long)r[0] * (unsigned long long)side.count) >> 32);
-            if (lane < IN) s_out[(size_t)b * IN + lane] = side.obs[(size_t)j * IN + lane];
-            else if (lane >= 32 && lane < 32 + IN) s2_out[(size_t)b * IN + lane - 32] = side.obs2[(size_t)j * IN + lane - 32];
-            if (lane == 63) {
-                a_out[b] = side.act[j];
-                r_out[b] = side.rew[j];
-                d_out[b] = side.done[j];
-                if (idx_out) { idx_out[2 * b] = -1; idx_out[2 * b + 1] = j; }
-            }
-            return;
-        }
-    }
-    const long long back = avail > 0 ? (long long)(((unsigned long long)r[0] * (unsigned long long)avail) >> 32) : 0;
-    const int t = (int)(((k - 1 - back) % slots + slots) % slots), t1 = (t + 1) % slots;
-    const int e = (int)(((unsigned long long)r[1] * (unsigned long long)n_envs) >> 32);
-    const float *src = obs + ((size_t)t * n_envs + e) * IN, *src2 = obs + ((size_t)t1 * n_envs + e) * IN;
-    if (lane < IN) s_out[(size_t)b * IN + lane] = src[lane];
-    else if (lane >= 32 && lane < 32 + IN) s2_out[(size_t)b * IN + lane - 32] = src2[lane - 32];
-    if (lane == 63) {
-        const size_t q = (size_t)t * n_envs + e;
-        a_out[b] = act[q];
-        r_out[b] = rew[q];
-        d_out[b] = done[q];
-        if (idx_out) { idx_out[2 * b] = t; idx_out[2 * b + 1] = e; }
-    }
-}
-
 int check_ptrs(const tt_mlp_weights *w, bool critic) {
     if (!w) return 0;
     if (w->in_dim != IN || w->fc1_dims != H1 || w->fc2_dims != H2) return 0;
@@ -337,6 +278,10 @@ int launch(int n, const float *obs, const float *action, const tt_mlp_weights *w
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 
+__global__ __launch_bounds__(64) void k_ring_sample(const RingSample R) {
+    if ((int)blockIdx.x < R.batch) ring_sample_row(R, blockIdx.x, threadIdx.x);
+}
+
 }  // namespace
 
 extern "C" {
@@ -374,22 +319,41 @@ int tt_actor_act(int n, const float *obs, const tt_mlp_weights *w, float *ou_sta
     return launch<false>(n, obs, nullptr, w, mu_out, act, stream);
 }
 
-int tt_ring_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const float *obs, const float *act,
-                   const float *rew, const uint8_t *done, uint64_t seed, int reserve, const tt_side_buffer *side, float *s_out,
-                   float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out, tt_stream_t stream) {
-    if (batch < 0 || n_envs <= 0 || reserve < 0 || slots < 3 + reserve || !k_dev || !obs || !act || !rew || !done || !s_out || !a_out || !r_out ||
-        !s2_out || !d_out)
+static int make_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const float *obs, const float *act,
+                       const float *rew, const uint8_t *done, uint64_t seed, int reserve, const tt_side_buffer *side,
+                       float *s_out, float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out,
+                       RingSample &R) {
+    if (batch < 0 || n_envs <= 0 || reserve < 0 || slots < 3 + reserve || !k_dev || !obs || !act || !rew || !done || !s_out ||
+        !a_out || !r_out || !s2_out || !d_out)
         return TT_EINVAL;
     SideBuf sb{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (side && side->count > 0) {
         if (!side->obs || !side->act || !side->rew || !side->obs2 || !side->done) return TT_EINVAL;
         sb = SideBuf{side->obs, side->act, side->rew, side->obs2, side->done, side->count};
     }
-    if (batch == 0) return TT_OK;
-    hipLaunchKernelGGL(k_ring_sample, dim3(batch), dim3(64), 0, stream, batch, n_envs, slots,
-                       reinterpret_cast<const long long *>(k_dev), obs, act, rew, done, seed, reserve, sb, s_out, a_out, r_out,
-                       s2_out, d_out, idx_out);
+    R = RingSample{batch, n_envs, slots, reserve, reinterpret_cast<const long long *>(k_dev), obs, act, rew, done, seed, sb,
+                   s_out, a_out, r_out, s2_out, d_out, idx_out};
+    return TT_OK;
+}
+
+int tt_ring_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const float *obs, const float *act,
+                   const float *rew, const uint8_t *done, uint64_t seed, int reserve, const tt_side_buffer *side, float *s_out,
+                   float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out, tt_stream_t stream) {
+    RingSample R;
+    const int rc = make_sample(batch, n_envs, slots, k_dev, obs, act, rew, done, seed, reserve, side, s_out, a_out, r_out, s2_out,
+                               d_out, idx_out, R);
+    if (rc != TT_OK || batch == 0) return rc;
+    hipLaunchKernelGGL(k_ring_sample, dim3(batch), dim3(64), 0, stream, R);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+int tt_mlp_split_pack_and_sample(const tt_mlp_weights *w, int critic, void *ws, const tt_sample_args *a, tt_stream_t stream) {
+    if (!ws || !a || !check_ptrs(w, critic != 0)) return TT_EINVAL;
+    RingSample R;
+    const int rc = make_sample(a->batch, a->n_envs, a->slots, a->k_dev, a->obs, a->act, a->rew, a->done, a->seed, a->reserve,
+                               a->side, a->s_out, a->a_out, a->r_out, a->s2_out, a->d_out, a->idx_out, R);
+    if (rc != TT_OK) return rc;
+    return split_pack_and_sample(w, critic != 0, ws, R, stream);
 }
 
 int tt_critic_forward(int n, const float *obs, const float *action, const tt_mlp_weights *w, float *q_out,

@@ -73,6 +73,70 @@ __device__ __forceinline__ void finish_row(const int row, const float v, float *
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Uniform sampling WITH replacement from the trajectory ring (replay_buffer.py:23-34 draws np.random.choice(max_mem,
+// batch)): 64 lanes gather one sampled transition s, a, r, s', done into the batch buffers.  The ring's step counter is
+// read from device memory so that a captured hipGraph of learn() samples fresh indices every replay (the Philox counter
+// includes it).  An optional side buffer of stand-alone transitions (expert tuples re-inserted the way trainv2.py:457-466
+// `remember`s them) is part of the same uniform draw: with M side transitions and R intact ring transitions each of the
+// M + R is picked with probability 1/(M + R).  Used by k_ring_sample (csrc/ttnet.hip) and by the pack-and-sample launch
+// that opens a pipelined vector step (csrc/ttnet_split.hip).
+struct SideBuf {
+    const float *obs, *act, *rew, *obs2;
+    const uint8_t *done;
+    int count;
+};
+struct RingSample {
+    int batch, n_envs, slots, reserve;
+    const long long *k_dev;
+    const float *obs, *act, *rew;
+    const uint8_t *done;
+    unsigned long long seed;
+    SideBuf side;
+    float *s_out, *a_out, *r_out, *s2_out;
+    uint8_t *d_out;
+    int *idx_out;
+};
+
+__device__ inline void ring_sample_row(const RingSample &R, const int b, const int lane) {
+    const int n_envs = R.n_envs, slots = R.slots;
+    const long long k = *R.k_dev;                     // vector steps completed; transitions k-avail .. k-1 are intact
+    const long long cap = slots - 1 - R.reserve;      // reserve: slots a concurrent env step is overwriting (pipelined loop)
+    const long long avail = k < cap ? k : cap;
+    uint32_t r[4];
+    philox4x32((uint32_t)b, (uint32_t)k, (uint32_t)(k >> 32), 0x5A3Du, (uint32_t)R.seed, (uint32_t)(R.seed >> 32), r);
+    if (R.side.count > 0) {
+        const unsigned long long in_ring = (unsigned long long)avail * (unsigned long long)n_envs;
+        const unsigned long long u = ((unsigned long long)r[2] << 32) | r[3];
+        if (__umul64hi(u, in_ring + (unsigned long long)R.side.count) < (unsigned long long)R.side.count) {
+            const int j = (int)(((unsigned long long)r[0] * (unsigned long long)R.side.count) >> 32);
+            if (lane < IN) R.s_out[(size_t)b * IN + lane] = R.side.obs[(size_t)j * IN + lane];
+            else if (lane >= 32 && lane < 32 + IN) R.s2_out[(size_t)b * IN + lane - 32] = R.side.obs2[(size_t)j * IN + lane - 32];
+            if (lane == 63) {
+                R.a_out[b] = R.side.act[j];
+                R.r_out[b] = R.side.rew[j];
+                R.d_out[b] = R.side.done[j];
+                if (R.idx_out) { R.idx_out[2 * b] = -1; R.idx_out[2 * b + 1] = j; }
+            }
+            return;
+        }
+    }
+    const long long back = avail > 0 ? (long long)(((unsigned long long)r[0] * (unsigned long long)avail) >> 32) : 0;
+    const int t = (int)(((k - 1 - back) % slots + slots) % slots), t1 = (t + 1) % slots;
+    const int e = (int)(((unsigned long long)r[1] * (unsigned long long)n_envs) >> 32);
+    const float *src = R.obs + ((size_t)t * n_envs + e) * IN, *src2 = R.obs + ((size_t)t1 * n_envs + e) * IN;
+    if (lane < IN) R.s_out[(size_t)b * IN + lane] = src[lane];
+    else if (lane >= 32 && lane < 32 + IN) R.s2_out[(size_t)b * IN + lane - 32] = src2[lane - 32];
+    if (lane == 63) {
+        const size_t q = (size_t)t * n_envs + e;
+        R.a_out[b] = R.act[q];
+        R.r_out[b] = R.rew[q];
+        R.d_out[b] = R.done[q];
+        if (R.idx_out) { R.idx_out[2 * b] = t; R.idx_out[2 * b + 1] = e; }
+    }
+}
+
 inline Weights to_weights(const tt_mlp_weights *w) {
     return Weights{w->w1, w->b1, w->g1, w->be1, w->w2, w->b2, w->g2, w->be2, w->w3, w->b3, w->wa, w->ba};
 }
@@ -80,6 +144,7 @@ inline Weights to_weights(const tt_mlp_weights *w) {
 // csrc/ttnet_split.hip
 size_t split_ws_bytes();
 int split_pack(const tt_mlp_weights *w, bool critic, void *ws, long long *bump, hipStream_t stream);
+int split_pack_and_sample(const tt_mlp_weights *w, bool critic, void *ws, const RingSample &R, hipStream_t stream);
 int split_forward(bool critic, int n, const float *obs, const float *action, const tt_mlp_weights *w, float *out,
                   const ActArgs &act, hipStream_t stream);
 #ifdef TT_STAMPS

@@ -102,9 +102,8 @@ __device__ __forceinline__ f32x16 mfma_f16(const uint4 a, const uint4 b, const f
 //   fc1 [400,23] + bias -> w1p[s][t][plane][lane]: neuron 32t + r at inputs 16 s + 8 h + j (natural order; input 23
 //     carries the bias, the observation operand carries a 1 there);
 //   vec: g1*SX | be1*SX [2][416], b2 | g2 | be2 | w3 | wa | ba [6][320], zero beyond the real neurons; then b3.
-__global__ __launch_bounds__(256) void k_split_pack(const Weights W, const bool critic, unsigned char *__restrict__ ws,
-                                                    long long *__restrict__ bump) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void split_pack_body(const Weights &W, const bool critic, unsigned char *__restrict__ ws,
+                                                long long *__restrict__ bump, const int idx) {
     if (bump && idx == 0) *bump += 1;      // optional step counter of a pipelined loop (read by LATER launches only)
     constexpr int N2 = STEPS * T2 * 64, N1 = S1 * T1 * 64;
     if (idx < N2 + N1) {
@@ -154,6 +153,25 @@ __global__ __launch_bounds__(256) void k_split_pack(const Weights W, const bool 
     vec[i] = v;
 }
 constexpr int PACK_THREADS = (STEPS * T2 + S1 * T1) * 64 + VEC_BYTES / 4;
+constexpr int PACK_BLOCKS = (PACK_THREADS + 255) / 256;
+
+__global__ __launch_bounds__(256) void k_split_pack(const Weights W, const bool critic, unsigned char *__restrict__ ws,
+                                                    long long *__restrict__ bump) {
+    split_pack_body(W, critic, ws, bump, blockIdx.x * 256 + threadIdx.x);
+}
+
+// What opens a pipelined vector step, in ONE launch (two small kernels would each cost their ~4 us of launch and a
+// dependency gap on the loop's critical path): the policy's image from the actor's current weights, and the first batch of
+// this step's learn() from the replay ring (four sampled transitions per 256-thread workgroup).
+__global__ __launch_bounds__(256) void k_pack_and_sample(const Weights W, const bool critic, unsigned char *__restrict__ ws,
+                                                         const RingSample R) {
+    if ((int)blockIdx.x < PACK_BLOCKS) {
+        split_pack_body(W, critic, ws, nullptr, blockIdx.x * 256 + threadIdx.x);
+        return;
+    }
+    const int b = ((int)blockIdx.x - PACK_BLOCKS) * 4 + (threadIdx.x >> 6);
+    if (b < R.batch) ring_sample_row(R, b, threadIdx.x & 63);
+}
 
 template <bool CRITIC>
 __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int tile0, const float *__restrict__ obs,
@@ -415,8 +433,14 @@ int split_debug_block_stamps(unsigned long long *out, int nblocks) {
 size_t split_ws_bytes() { return (size_t)WS_BYTES; }
 
 int split_pack(const tt_mlp_weights *w, bool critic, void *ws, long long *bump, hipStream_t stream) {
-    hipLaunchKernelGGL(k_split_pack, dim3((PACK_THREADS + 255) / 256), dim3(256), 0, stream, to_weights(w), critic,
+    hipLaunchKernelGGL(k_split_pack, dim3(PACK_BLOCKS), dim3(256), 0, stream, to_weights(w), critic,
                        reinterpret_cast<unsigned char *>(ws), bump);
+    return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+int split_pack_and_sample(const tt_mlp_weights *w, bool critic, void *ws, const RingSample &R, hipStream_t stream) {
+    hipLaunchKernelGGL(k_pack_and_sample, dim3(PACK_BLOCKS + (R.batch + 3) / 4), dim3(256), 0, stream, to_weights(w), critic,
+                       reinterpret_cast<unsigned char *>(ws), R);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 

@@ -22,6 +22,15 @@ def supported(net):
             and tuple(net.fc2.weight.shape) == (300, 400) and net.bn1.eps == 1e-5 and net.bn2.eps == 1e-5)
 
 
+def pack_and_sample(net, index, sample_args):
+    """pack() and the replay draw described by `sample_args` (TrajectoryRing.sample_args) in ONE launch
+    (tt_mlp_split_pack_and_sample): what opens a pipelined vector step."""
+    w = packed_weights_of(net, index)
+    dev = net.fc2.weight.device
+    L.check(L.load().tt_mlp_split_pack_and_sample(C.byref(w), 1 if hasattr(net, "action_value") else 0, C.c_void_p(w.split_ws),
+                                                  C.byref(sample_args), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+
+
 def _fill_weights(net, w):
     head = net.mu if hasattr(net, "mu") else net.q
     for name, t in (("w1", net.fc1.weight), ("b1", net.fc1.bias), ("g1", net.bn1.weight), ("be1", net.bn1.bias),

@@ -153,6 +153,27 @@ class TrajectoryRing:
         self.k = int(sd["k"])               # the counters come back whether or not the contents did
         self.k_dev.fill_(self.k)
 
+    def _batch_bufs(self, batch_size):
+        if getattr(self, "_bufs", None) is None or self._bufs[0].shape[0] != batch_size:
+            f = dict(dtype=torch.float32, device=self.device)
+            d = self.obs.shape[2]
+            self._bufs = (torch.empty((batch_size, d), **f), torch.empty((batch_size, 1), **f), torch.empty(batch_size, **f),
+                          torch.empty((batch_size, d), **f), torch.empty(batch_size, dtype=torch.uint8, device=self.device),
+                          torch.empty((batch_size, 2), dtype=torch.int32, device=self.device))
+        return self._bufs
+
+    def sample_args(self, batch_size, seed=0, k_dev=None, reserve=0):
+        """tt_sample_args for one draw into the ring's batch buffers (include/ttenv.h); keeps what it points at alive."""
+        from ddpg_trucktrailer_amd import _lib as L
+        s, a, r, s2, dn, idx = self._batch_bufs(batch_size)
+        p = lambda t: t.data_ptr()
+        side = self._side_struct()
+        self._side_keep = side
+        import ctypes as C
+        return L.TTSampleArgs(batch_size, self.n, self.slots, int(reserve), p(self.k_dev if k_dev is None else k_dev),
+                              p(self.obs), p(self.act), p(self.rew), p(self.done), int(seed) & (2 ** 64 - 1),
+                              C.pointer(side) if side is not None else None, p(s), p(a), p(r), p(s2), p(dn), p(idx))
+
     def sample_fused(self, batch_size, seed=0, return_index=False, done_as_bool=True, k_dev=None, reserve=0):
         """sample() as ONE HIP launch (tt_ring_sample): Philox indices keyed by (seed, k_dev) + gather.
         done_as_bool=False returns the raw uint8 flags (no conversion launch; what the fused learner takes).
@@ -160,13 +181,7 @@ class TrajectoryRing:
         loop samples BESIDE the env step of the same vector step: include/ttenv.h, tt_ring_sample)."""
         import ctypes as C
         from ddpg_trucktrailer_amd import _lib as L
-        if getattr(self, "_bufs", None) is None or self._bufs[0].shape[0] != batch_size:
-            f = dict(dtype=torch.float32, device=self.device)
-            d = self.obs.shape[2]
-            self._bufs = (torch.empty((batch_size, d), **f), torch.empty((batch_size, 1), **f), torch.empty(batch_size, **f),
-                          torch.empty((batch_size, d), **f), torch.empty(batch_size, dtype=torch.uint8, device=self.device),
-                          torch.empty((batch_size, 2), dtype=torch.int32, device=self.device))
-        s, a, r, s2, dn, idx = self._bufs
+        s, a, r, s2, dn, idx = self._batch_bufs(batch_size)
         p = lambda t: C.c_void_p(t.data_ptr())
         side = self._side_struct()
         L.check(L.load().tt_ring_sample(batch_size, self.n, self.slots, p(self.k_dev if k_dev is None else k_dev), p(self.obs),

@@ -137,15 +137,21 @@ class DDPGRollout:
 
     # -------------------------------------------------------------- learning
     def _sample(self, u):
-        key = (self.seed + u * _SEED_STRIDE) & (2 ** 64 - 1)
+        key = self._sample_key(u)
         if self.device.type == "cuda":
             if self.pipeline:      # beside the env step of the same vector step: its slot is not part of the window
                 return self.ring.sample_fused(self.batch_size, seed=key, done_as_bool=False, k_dev=self.k_pipe_dev, reserve=1)
             return self.ring.sample_fused(self.batch_size, seed=key, done_as_bool=self.learner is None)
         return self.ring.sample(self.batch_size)
 
-    def _learn_once(self, u=0):
-        s, a, r, s2, d = self._sample(u)
+    def _sample_key(self, u):
+        return (self.seed + u * _SEED_STRIDE) & (2 ** 64 - 1)
+
+    def _learn_once(self, u=0, presampled=False):
+        if presampled:         # the step's opening launch already drew this batch into the ring's buffers
+            s, a, r, s2, d = self.ring._bufs[:5]
+        else:
+            s, a, r, s2, d = self._sample(u)
         if self.learner is not None:
             # (pipelined order) the last update of a vector step moves the sampling window on
             last = self.pipeline and u == self.updates_per_step - 1
@@ -153,9 +159,9 @@ class DDPGRollout:
         else:
             self.agent.learn_batch(s, a, r, s2, d)
 
-    def _learn_all(self):
+    def _learn_all(self, presampled=False):
         for u in range(self.updates_per_step):
-            self._learn_once(u)
+            self._learn_once(u, presampled and u == 0)
 
     def learn(self):
         if self.ring.k < 2:
@@ -207,14 +213,18 @@ class DDPGRollout:
         it off learn()'s path) ROCm's graph executor runs the two branches one after the other (tools/graph_probe2.py).
         dp_capture: only learn()'s first segment (up to the critic's gradient) goes beside the policy; _dp_step does the rest."""
         cur, side = torch.cuda.current_stream(self.device), self._pipe_side
-        fused.pack(self.agent.actor, 0)
+        if learn:      # ... and the first batch of this step's learn(), in the same launch (one kernel and one gap less)
+            fused.pack_and_sample(self.agent.actor, 0, self.ring.sample_args(
+                self.batch_size, seed=self._sample_key(0), k_dev=self.k_pipe_dev, reserve=1))
+        else:
+            fused.pack(self.agent.actor, 0)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             if dp_capture:
-                self.learner.phase_a(*self._sample(0), fuse_adam=False,
+                self.learner.phase_a(*self.ring._bufs[:5], fuse_adam=False,
                                      window_dev=self.k_pipe_dev if self.updates_per_step == 1 else None)
             elif learn:
-                self._learn_all()
+                self._learn_all(presampled=True)
             else:
                 self.k_pipe_dev.add_(1)                     # no learn() yet: the window still moves with the steps
         self._act_and_step(k)

@@ -249,6 +249,22 @@ int tt_ring_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const
                    const float *rew, const uint8_t *done, uint64_t seed, int reserve, const tt_side_buffer *side, float *s_out,
                    float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out, tt_stream_t stream);
 
+/* tt_mlp_split_pack + tt_ring_sample in ONE launch: what opens a vector step of a pipelined loop (the policy's image from
+ * the actor's current weights; the first batch of the step's learn()).  The members of tt_sample_args are tt_ring_sample's
+ * arguments. */
+typedef struct tt_sample_args {
+    int32_t batch, n_envs, slots, reserve;
+    const int64_t *k_dev;
+    const float *obs, *act, *rew;
+    const uint8_t *done;
+    uint64_t seed;
+    const tt_side_buffer *side;
+    float *s_out, *a_out, *r_out, *s2_out;
+    uint8_t *d_out;
+    int32_t *idx_out;
+} tt_sample_args;
+int tt_mlp_split_pack_and_sample(const tt_mlp_weights *w, int critic, void *ws, const tt_sample_args *sample, tt_stream_t stream);
+
 /* CriticNetwork.forward (DDPG/networks.py:55-68) for n rows: q_out [n]. */
 int tt_critic_forward(int n, const float *obs /*[n,23]*/, const float *action /*[n]*/, const tt_mlp_weights *w,
                       float *q_out, tt_stream_t stream);
