@@ -123,6 +123,12 @@ _SIGNATURES = {
                                        C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights), _I, _P, _P, _P,
                                        _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.POINTER(TTTdInput), C.POINTER(TTDqdaInput), _P]),
+    "tt_mlp_backward_rows_pair": (C.c_int, [_I, C.c_float, _P, C.POINTER(TTMlpWeights), C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs),
+                                            C.POINTER(TTTdInput), _P, C.POINTER(TTMlpWeights), C.POINTER(TTMlpSaved),
+                                            C.POINTER(TTMlpBwdWs), _P]),
+    "tt_mlp_backward_weights": (C.c_int, [_I, _I, _P, _P, C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights),
+                                          _P, _P, C.c_float, _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
+                                          C.c_float, C.c_float, _P]),
     "tt_adam_soft_update": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                       C.c_float, C.c_float, _P]),
     "tt_td_target": (C.c_int, [_I, _P, _P, _P, C.c_float, _P, _P, _P]),

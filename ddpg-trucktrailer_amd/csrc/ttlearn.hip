@@ -377,6 +377,8 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
 //   mode 0: d_out[b] is given (gradient w.r.t. `out`)
 //   mode 1: d_out[b] = scale * (out[b] - y[b])          critic MSE: d/dq mean((y - q)^2), scale = 2/B
 //   mode 2: d_out[b] = scale * aux[b]                    actor: d/dmu mean(-Q), aux = dQ/da, scale = -1/B
+//   mode 3: unit gradient 1 at the head's PRE-activation of every row (no tanh factor): the per-row gradients of a row are
+//           linear in that number, so the real ones are these times the row's d(loss)/d(pre) -- applied by k_bwd_weights
 // actor (CRITIC = false): `out` is mu = tanh(pre) and the head gradient is d_out * (1 - mu^2).
 // Writes dpre [B], dz [B,300] (grad at the ReLU-masked LayerNorm2 output), dx2 [B,300] (grad at fc2's output),
 // dy1 [B,400] (grad at the ReLU-masked LayerNorm1 output), dx1 [B,400] (grad at fc1's output).
@@ -470,6 +472,7 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
         if (ok) {
             float g = mode == 0 ? gin[rr] : (mode == 1 ? scale * (outv[rr] - (with_td ? y_td : yin[rr])) : scale * gin[rr]);
             if (!CRITIC) g *= (1.f - outv[rr] * outv[rr]);
+            if (mode == 3) g = 1.f;       // unit backward: every per-row gradient below is linear in g (see k_bwd_rows_pair)
             dpre = g;
         }
         float dxh[C2], s1 = 0.f, s2 = 0.f;
@@ -615,6 +618,28 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows(const int n, const int mod
     bwd_rows_body<CRITIC>(n, mode, scale, d_out, out, y, aux, W, sv, o, td, dx2_s, red, blockIdx.x * TR);
 }
 
+// The critic's per-row backward (TD prologue, mode 1) and the ACTOR's unit backward (mode 3) in one launch, on different
+// workgroups.  The actor's per-row gradients are linear in the row's d(loss)/d(pre-tanh) = -(1/B) dQ/da (1 - mu^2), and dQ/da
+// needs the UPDATED critic (DDPG_agent.py:100-103) -- but everything else of the actor's backward (ReLU masks, both
+// LayerNorm backwards, dH1 = dX2 * W2) only needs what the forward saved.  So that part runs HERE, beside the critic's
+// backward, for a unit gradient, and k_bwd_weights multiplies row b by the real number once the critic has been updated and
+// dQ/da is known: the actor's backward is off the chain's critical path.
+__global__ __launch_bounds__(64 * NW) void k_bwd_rows_pair(const int n, const float scale_c, const float *__restrict__ q_out,
+                                                           const Weights Wc, const Saved sv_c, const BwdOut o_c, const TdIn td,
+                                                           const float *__restrict__ mu_out, const Weights Wa, const Saved sv_a,
+                                                           const BwdOut o_a) {
+    __shared__ __attribute__((aligned(16))) float dx2_s[TR * DS];
+    __shared__ float red[NW * TR];
+    const int nb = (n + TR - 1) / TR;
+    if ((int)blockIdx.x < nb) {
+        bwd_rows_body<true>(n, 1, scale_c, nullptr, q_out, nullptr, nullptr, Wc, sv_c, o_c, td, dx2_s, red, blockIdx.x * TR);
+    } else {
+        const TdIn none{};
+        bwd_rows_body<false>(n, 3, 1.f, nullptr, mu_out, nullptr, nullptr, Wa, sv_a, o_a, none, dx2_s, red,
+                             ((int)blockIdx.x - nb) * TR);
+    }
+}
+
 // The actor's step through the updated critic (DDPG_agent.py:100-103) for the 16 rows of a workgroup in ONE launch:
 // Q(s, mu(s)) with dQ/da on the critic (forward only), then the actor's per-row backward with d(loss)/d(mu) =
 // scale * dQ/da.  Both halves partition the batch by the same rows, so nothing crosses workgroups between them.
@@ -677,6 +702,14 @@ __device__ __forceinline__ void adam_apply(const AdamFused &A, const int t, cons
     adam_finish(A, t, i, grad, adam_load(A, t, i), bc1, sqrt_bc2);
 }
 
+// Optional per-row factor of k_bwd_weights' inputs: row b of dpre / dz / dx2 / dy1 / dx1 (a unit backward, mode 3) counts
+// f(b) = scale * dq_da[b] * (1 - mu[b]^2) times: the actor's d(loss)/d(pre-tanh) for loss = -mean Q(s, mu(s)).
+struct RowScale {
+    const float *__restrict__ dq_da, *__restrict__ mu;
+    float scale;
+};
+constexpr int MAXB = 1024;     // rows whose factors fit the LDS table of k_bwd_weights<true> (tt_mlp_backward_weights checks)
+
 struct Grads {
     float *__restrict__ w1, *__restrict__ b1, *__restrict__ g1, *__restrict__ be1, *__restrict__ w2, *__restrict__ b2,
         *__restrict__ g2, *__restrict__ be2, *__restrict__ w3, *__restrict__ b3, *__restrict__ wa, *__restrict__ ba;
@@ -688,10 +721,20 @@ constexpr int NCAT = 10;                            // db2 dg2 dbe2 db1 dg1 dbe1
 constexpr int SUMB_ACTOR = 3 * 5 + 3 * 7 + 5 + 1;   // 64-column chunks per quantity: 300 -> 5, 400 -> 7, 1 -> 1
 constexpr int SUMB_CRITIC = SUMB_ACTOR + 2 * 5;
 
+template <bool ROWSCALE>
 __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int critic, const float *__restrict__ obs,
                                                      const float *__restrict__ action, const Saved sv,
-                                                     const BwdOut d, const Grads G, const AdamFused A) {
+                                                     const BwdOut d, const Grads G, const AdamFused A, const RowScale RS) {
     __shared__ __attribute__((aligned(16))) float part[4][4][256];     // [wave][tile][lane*4 + r]
+    __shared__ float f_s[ROWSCALE ? MAXB : 1];                         // the rows' factors, computed once per workgroup
+    if (ROWSCALE) {
+        for (int b = threadIdx.x; b < n; b += 256) {
+            const float m = RS.mu[b];
+            f_s[b] = RS.scale * RS.dq_da[b] * (1.f - m * m);
+        }
+        __syncthreads();
+    }
+    auto row_factor = [&](const RowScale &, const int b) -> float { return ROWSCALE ? f_s[b] : 1.f; };
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int blk = blockIdx.x;
     float bc1 = 1.f, sqrt_bc2 = 1.f;
@@ -719,7 +762,7 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int b = b0 + 4 * l4 + ks;                                          // permuted k order
-                av[ks] = (b < b_hi && jok) ? d.dx2[(size_t)b * H2 + j] : 0.f;           // A[i = j][k = b]
+                av[ks] = (b < b_hi && jok) ? d.dx2[(size_t)b * H2 + j] * row_factor(RS, b) : 0.f;   // A[i = j][k = b]
                 bv[ks] = (b < b_hi && cok) ? *reinterpret_cast<const float4 *>(sv.h1 + (size_t)b * H1 + c0)
                                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -770,7 +813,7 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int b = b0 + 4 * l4 + ks;
-                av[ks] = b < b_hi ? d.dx1[(size_t)b * H1 + j] : 0.f;
+                av[ks] = b < b_hi ? d.dx1[(size_t)b * H1 + j] * row_factor(RS, b) : 0.f;
                 b0v[ks] = b < b_hi ? obs[(size_t)b * IN + l15] : 0.f;                            // columns 0..15
                 b1v[ks] = (b < b_hi && 16 + l15 < IN) ? obs[(size_t)b * IN + 16 + l15] : 0.f;    // 16..22
             }
@@ -844,22 +887,22 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
             int b = lo;
             if (pb) {
                 for (; b + 16 <= hi; b += 16) {
-                    float t[16], u2[16];
+                    float t[16], u2[16], f[16];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) { t[u] = pa[(size_t)(b + u) * sa]; u2[u] = pb[(size_t)(b + u) * sb]; }
+                    for (int u = 0; u < 16; ++u) { t[u] = pa[(size_t)(b + u) * sa]; u2[u] = pb[(size_t)(b + u) * sb]; f[u] = row_factor(RS, b + u); }
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) acc += t[u] * u2[u];
+                    for (int u = 0; u < 16; ++u) acc += (t[u] * f[u]) * u2[u];
                 }
-                for (; b < hi; ++b) acc += pa[(size_t)b * sa] * pb[(size_t)b * sb];
+                for (; b < hi; ++b) acc += (pa[(size_t)b * sa] * row_factor(RS, b)) * pb[(size_t)b * sb];
             } else {
                 for (; b + 16 <= hi; b += 16) {
-                    float t[16];
+                    float t[16], f[16];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) t[u] = pa[(size_t)(b + u) * sa];
+                    for (int u = 0; u < 16; ++u) { t[u] = pa[(size_t)(b + u) * sa]; f[u] = row_factor(RS, b + u); }
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) acc += t[u];
+                    for (int u = 0; u < 16; ++u) acc += t[u] * f[u];
                 }
-                for (; b < hi; ++b) acc += pa[(size_t)b * sa];
+                for (; b < hi; ++b) acc += pa[(size_t)b * sa] * row_factor(RS, b);
             }
         }
         part[wave][0][lane] = acc;
@@ -1068,8 +1111,17 @@ static int backward_impl(int n, int critic, int mode, float scale, const float *
                   const_cast<float *>(grads->g2), const_cast<float *>(grads->be2), const_cast<float *>(grads->w3),
                   const_cast<float *>(grads->b3), const_cast<float *>(grads->wa), const_cast<float *>(grads->ba)};
     const int sum_blocks = critic ? SUMB_CRITIC : SUMB_ACTOR;
-    hipLaunchKernelGGL(k_bwd_weights, dim3(NU2 + NU1 + sum_blocks), block, 0, stream, n, critic, obs, action, sv, o, G, A);
+    const RowScale none{nullptr, nullptr, 1.f};
+    hipLaunchKernelGGL(k_bwd_weights<false>, dim3(NU2 + NU1 + sum_blocks), block, 0, stream, n, critic, obs, action, sv, o, G, A, none);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+static bool saved_ok(const tt_mlp_saved *s) { return s && s->xh1 && s->h1 && s->xh2 && s->h2 && s->rstd1 && s->rstd2; }
+static bool ws_ok(const tt_mlp_bwd_ws *w) { return w && w->dpre && w->dz && w->dx2 && w->dy1 && w->dx1; }
+static Grads to_grads(const tt_mlp_weights *g) {
+    return Grads{const_cast<float *>(g->w1), const_cast<float *>(g->b1), const_cast<float *>(g->g1), const_cast<float *>(g->be1),
+                 const_cast<float *>(g->w2), const_cast<float *>(g->b2), const_cast<float *>(g->g2), const_cast<float *>(g->be2),
+                 const_cast<float *>(g->w3), const_cast<float *>(g->b3), const_cast<float *>(g->wa), const_cast<float *>(g->ba)};
 }
 
 int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
@@ -1096,6 +1148,59 @@ int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *
     A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.weight_decay = weight_decay; A.tau = tau;
     A.on = 1;
     return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, td, dq, stream);
+}
+
+int tt_mlp_backward_rows_pair(int n, float scale_critic, const float *q_out, const tt_mlp_weights *critic,
+                              const tt_mlp_saved *saved_critic, const tt_mlp_bwd_ws *ws_critic, const tt_td_input *tdi,
+                              const float *mu_out, const tt_mlp_weights *actor, const tt_mlp_saved *saved_actor,
+                              const tt_mlp_bwd_ws *ws_actor, tt_stream_t stream) {
+    if (n <= 0 || !q_out || !mu_out || !ok_shape(critic, true) || !ok_shape(actor, false) || !saved_ok(saved_critic) ||
+        !saved_ok(saved_actor) || !ws_ok(ws_critic) || !ws_ok(ws_actor) || !tdi || ws_critic->dx2 == ws_actor->dx2)
+        return TT_EINVAL;
+    const tt_mlp_weights *tw = tdi->target_critic;
+    if (!tdi->z_state || !tdi->mu_target || !ok_shape(tw, true) || !tdi->reward || !tdi->done || !tdi->y_out) return TT_EINVAL;
+    const TdIn td{tdi->z_state, tdi->mu_target, tdi->reward, tdi->done, tw->wa, tw->ba, tw->w3, tw->b3, tdi->gamma,
+                  tdi->y_out, tdi->q_out, reinterpret_cast<long long *>(tdi->step_dev),
+                  reinterpret_cast<long long *>(tdi->window_dev)};
+    const Saved sc{saved_critic->xh1, saved_critic->h1, saved_critic->xh2, saved_critic->h2, saved_critic->rstd1, saved_critic->rstd2};
+    const Saved sa{saved_actor->xh1, saved_actor->h1, saved_actor->xh2, saved_actor->h2, saved_actor->rstd1, saved_actor->rstd2};
+    const BwdOut oc{ws_critic->dpre, ws_critic->dz, ws_critic->dx2, ws_critic->dy1, ws_critic->dx1};
+    const BwdOut oa{ws_actor->dpre, ws_actor->dz, ws_actor->dx2, ws_actor->dy1, ws_actor->dx1};
+    hipLaunchKernelGGL(k_bwd_rows_pair, dim3(2 * ((n + TR - 1) / TR)), dim3(64 * NW), 0, stream, n, scale_critic, q_out,
+                       to_weights(critic), sc, oc, td, mu_out, to_weights(actor), sa, oa);
+    return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *action, const tt_mlp_saved *saved,
+                            const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const float *row_dq_da, const float *row_mu,
+                            float row_scale, int count, float *const *params, float *const *exp_avg, float *const *exp_avg_sq,
+                            float *const *targets, const int64_t *step_dev, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, float tau, tt_stream_t stream) {
+    if (n <= 0 || !obs || (critic && !action) || !saved_ok(saved) || !ws_ok(ws) || !ok_shape(grads, critic != 0) ||
+        ((row_dq_da == nullptr) != (row_mu == nullptr)))
+        return TT_EINVAL;
+    AdamFused A{};
+    if (count) {        // Adam + soft update applied in the same launch (one rank); count = 0: gradients only
+        if (count != (critic ? 12 : 10) || !params || !exp_avg || !exp_avg_sq || !step_dev) return TT_EINVAL;
+        for (int i = 0; i < count; ++i) {
+            if (!params[i] || !exp_avg[i] || !exp_avg_sq[i]) return TT_EINVAL;
+            A.p[i] = params[i]; A.m[i] = exp_avg[i]; A.v[i] = exp_avg_sq[i]; A.tgt[i] = targets ? targets[i] : nullptr;
+        }
+        A.step_dev = reinterpret_cast<const long long *>(step_dev);
+        A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.weight_decay = weight_decay; A.tau = tau;
+        A.on = 1;
+    }
+    const Saved sv{saved->xh1, saved->h1, saved->xh2, saved->h2, saved->rstd1, saved->rstd2};
+    const BwdOut o{ws->dpre, ws->dz, ws->dx2, ws->dy1, ws->dx1};
+    const RowScale rs{row_dq_da, row_mu, row_scale};
+    const dim3 grid(NU2 + NU1 + (critic ? SUMB_CRITIC : SUMB_ACTOR));
+    if (row_dq_da) {
+        if (n > MAXB) return TT_EINVAL;
+        hipLaunchKernelGGL(k_bwd_weights<true>, grid, dim3(256), 0, stream, n, critic, obs, action, sv, o, to_grads(grads), A, rs);
+    } else {
+        hipLaunchKernelGGL(k_bwd_weights<false>, grid, dim3(256), 0, stream, n, critic, obs, action, sv, o, to_grads(grads), A, rs);
+    }
+    return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 
 int tt_adam_soft_update(int count, float *const *params, const float *const *grads, float *const *exp_avg,

@@ -77,6 +77,9 @@ class FusedLearner:
         self.ws_t = dict(dpre=torch.empty(B, **f), dz=torch.empty((B, 300), **f), dx2=torch.empty((B, 300), **f),
                          dy1=torch.empty((B, 400), **f), dx1=torch.empty((B, 400), **f))
         self.ws = L.TTMlpBwdWs(**{k: v.data_ptr() for k, v in self.ws_t.items()})
+        # the actor's per-row gradients have a workspace of their own: its (unit) backward runs beside the critic's
+        self.ws_actor_t = {k: torch.empty_like(v) for k, v in self.ws_t.items()}
+        self.ws_actor = L.TTMlpBwdWs(**{k: v.data_ptr() for k, v in self.ws_actor_t.items()})
         self.mu_t, self.q_t, self.y, self.q, self.mu, self.q_pi, self.dq_da = (torch.empty(B, **f) for _ in range(7))
         self.step_dev = torch.zeros((), dtype=torch.int64, device=dev)      # learn() calls done (Adam's step count)
         self.z_t = torch.empty((B, 300), **f)          # the target critic's state branch on s' (before the action enters)
@@ -161,23 +164,33 @@ class FusedLearner:
                          done=done_u8.data_ptr(), gamma=float(ag.gamma), y_out=self.y.data_ptr(),
                          q_out=self.q_t.data_ptr(), step_dev=self.step_dev.data_ptr(),
                          window_dev=window_dev.data_ptr() if window_dev is not None else None)
-        if fuse_adam:
-            self._bwd_adam(self.critic, self.hyp_critic, ag.tau, 1, 2.0 / B, states, actions, self.q, td=td)
-        else:
-            self._bwd(self.critic, 1, 2.0 / B, states, actions, self.q, td=td)
+        # ... and, on other workgroups of the same launch, the ACTOR's per-row backward for a unit gradient: it is linear in
+        # the row's d(loss)/d(pre-tanh), which needs the updated critic and is applied in phase_b (include/ttenv.h)
+        L.check(self.lib.tt_mlp_backward_rows_pair(B, 2.0 / B, _p(self.q), C.byref(fused.weights_of(ag.critic)),
+                                                   C.byref(self.critic.saved), C.byref(self.ws), C.byref(td), _p(self.mu),
+                                                   C.byref(fused.weights_of(ag.actor)), C.byref(self.actor.saved),
+                                                   C.byref(self.ws_actor), self._stream()))
+        self._weights(self.critic, self.hyp_critic, ag.tau, states, actions, self.ws, adam=fuse_adam)
+
+    def _weights(self, st, hyp, tau, obs, action, ws, adam, row=None):
+        """The weight-gradient launch (tt_mlp_backward_weights), with Adam + soft update in it when `adam`."""
+        lr, b1, b2, eps, wd = hyp
+        dq, mu, sc = row if row is not None else (None, None, 1.0)
+        L.check(self.lib.tt_mlp_backward_weights(self.B, 1 if st.critic else 0, _p(obs), _p(action), C.byref(st.saved), C.byref(ws),
+                                                 C.byref(st.gstruct), _p(dq), _p(mu), float(sc), st.count if adam else 0,
+                                                 st.a_p, st.a_m, st.a_v, st.a_t, _p(self.step_dev), lr, b1, b2, eps, wd, tau,
+                                                 self._stream()))
 
     def phase_b(self, states, separate_adam):
         """[critic Adam/soft update when not already applied,] then the actor step through the UPDATED critic
-        (DDPG_agent.py:100-104): Q(s, mu(s)) with dQ/da, actor backward (+ its Adam unless separate_adam)."""
+        (DDPG_agent.py:100-104): Q(s, mu(s)) with dQ/da (a critic forward), and the actor's weight gradients from its unit
+        per-row backward scaled by -(1/B) dQ/da (1 - mu^2) per row (+ its Adam unless separate_adam)."""
         ag, B = self.agent, self.B
         if separate_adam:
             self._adam(self.critic, self.hyp_critic, ag.tau)
-        # Q(s, mu(s)) with dQ/da and the actor's per-row backward share one launch (tt_dqda_input): same row partition
-        dq = L.TTDqdaInput(critic=C.pointer(fused.weights_of(ag.critic)), q_out=self.q_pi.data_ptr(), dq_da=self.dq_da.data_ptr())
-        if separate_adam:
-            self._bwd(self.actor, 2, -1.0 / B, states, None, self.mu, dq=dq)
-        else:
-            self._bwd_adam(self.actor, self.hyp_actor, ag.tau, 2, -1.0 / B, states, None, self.mu, dq=dq)
+        self._fwd(ag.critic, states, self.mu, self.q_pi, dq_da=self.dq_da)
+        self._weights(self.actor, self.hyp_actor, ag.tau, states, None, self.ws_actor, adam=not separate_adam,
+                      row=(self.dq_da, self.mu, -1.0 / B))
 
     def phase_c(self):
         self._adam(self.actor, self.hyp_actor, self.agent.tau)

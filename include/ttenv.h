@@ -355,6 +355,27 @@ int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *
                          const int64_t *step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
                          float tau, const tt_td_input *td, const tt_dqda_input *dq, tt_stream_t stream);
 
+/* learn()'s second phase in the form the rollout loop uses.  The actor's per-row backward is linear in the row's
+ * d(loss)/d(pre-tanh) = -(1/B) dQ/da (1 - mu^2), and only dQ/da needs the UPDATED critic (DDPG_agent.py:100-103): so
+ *   tt_mlp_backward_rows_pair   runs the critic's per-row backward (mode 1, TD target in its prologue: tt_td_input) and, on
+ *                               other workgroups of the SAME launch, the actor's per-row backward for a unit gradient
+ *                               (ws_actor receives d(.)/d(pre-tanh) = 1 per row; ws_critic != ws_actor);
+ *   tt_mlp_backward_weights     is the weight-gradient launch alone (what tt_mlp_backward[_adam] runs second): gradients of
+ *                               every parameter from saved + ws, with row b of ws counted row_scale * row_dq_da[b] *
+ *                               (1 - row_mu[b]^2) times when row_dq_da / row_mu are given (both or neither), and with
+ *                               Adam + soft update in the same launch when count != 0 (arguments as tt_mlp_backward_adam).
+ * Sequence of a learn(): tt_mlp_forward_multi, tt_mlp_backward_rows_pair, tt_mlp_backward_weights(critic), tt_mlp_forward_save
+ * (critic on (s, mu(s)) with dq_da), tt_mlp_backward_weights(actor, row_dq_da = dq_da, row_mu = mu, row_scale = -1/B). */
+int tt_mlp_backward_rows_pair(int n, float scale_critic, const float *q_out, const tt_mlp_weights *critic,
+                              const tt_mlp_saved *saved_critic, const tt_mlp_bwd_ws *ws_critic, const tt_td_input *td,
+                              const float *mu_out, const tt_mlp_weights *actor, const tt_mlp_saved *saved_actor,
+                              const tt_mlp_bwd_ws *ws_actor, tt_stream_t stream);
+int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *action, const tt_mlp_saved *saved,
+                            const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const float *row_dq_da, const float *row_mu,
+                            float row_scale, int count, float *const *params, float *const *exp_avg, float *const *exp_avg_sq,
+                            float *const *targets, const int64_t *step_dev, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, float tau, tt_stream_t stream);
+
 /* optimizer.step() of torch.optim.Adam (weight decay folded into the gradient; networks.py:49-50,133) for `count`
  * (<= 12) parameter tensors in one launch, then the soft update of the matching target tensors
  * (Agent.update_network_parameters, DDPG_agent.py:108-131; targets NULL = none).  The arrays are HOST arrays of device
