@@ -321,7 +321,10 @@ def main():
                  "step t on a second graph branch; the policy acts with the weights learn() of step t-1 left"
                  if loop.pipeline else "serial: policy, env step, then learn() on a window that includes the new step")
         extra = {"batch": args.batch, "updates_per_step": args.updates_per_step,
-                 "replay_capacity": args.replay_slots * n, "launch": launch, "order": order}
+                 "replay_capacity": args.replay_slots * n, "launch": launch, "order": order,
+                 "env_steps_per_update": n / args.updates_per_step,
+                 "note": ("throughput of the configuration BASELINE.json names; how the same loop trains at this and at other "
+                          "update ratios (--updates-per-step): profiles/r02_training_behaviour.md")}
 
     def sync_all():
         torch.cuda.synchronize()

@@ -87,7 +87,7 @@ def pack(net, index, bump=None):
 
 @contextlib.contextmanager
 def exact_f32(net):
-    """Within the block, forwards of `net` run on the exact-f32 MFMA kernel whatever the batch (the split-bf16 kernel's
+    """Within the block, forwards of `net` run on the exact-f32 MFMA kernel whatever the batch (the split-f16 kernel's
     bit-reference; tests and A/B timing)."""
     w = weights_of(net)
     ws, w.split_ws = w.split_ws, None

@@ -1,5 +1,5 @@
 """GPU (-m gpu): the fused actor / critic inference kernels -- exact-f32 MFMA (csrc/ttnet.hip) and, from 1024 rows,
-split-bf16 MFMA (csrc/ttnet_split.hip) -- against the plain torch modules (f32 reference of the same op), tolerance
+split-f16 MFMA (csrc/ttnet_split.hip) -- against the plain torch modules (f32 reference of the same op), tolerance
 2e-5 absolute on tanh outputs / 2e-5 relative on Q; the two kernels against each other and against torch in f64."""
 import math
 
@@ -26,7 +26,7 @@ def _nets(dev, seed=0):
 @pytest.mark.parametrize("n", [1, 63, 64, 1000, 1024, 1153, 65536])
 @pytest.mark.parametrize("kernel", ["default", "f32"])
 def test_actor_and_critic_forward_match_torch(gpu_device, n, kernel):
-    """default = what the launcher picks (exact f32 below 1024 rows, split-bf16 from there); f32 = exact f32 forced."""
+    """default = what the launcher picks (exact f32 below 1024 rows, split-f16 from there); f32 = exact f32 forced."""
     import contextlib
     import torch
     from ddpg_trucktrailer_amd import fused
@@ -46,9 +46,10 @@ def test_actor_and_critic_forward_match_torch(gpu_device, n, kernel):
     assert (q - ref_q).abs().max().item() <= 2e-5 * max(1.0, ref_q.abs().max().item())
 
 
-def test_split_bf16_kernel_is_f32_accurate(gpu_device):
-    """The split-bf16 kernel (three exact bf16 pieces per f32 operand, 6 of the 9 partial products) against the
-    exact-f32 kernel and against the modules evaluated in f64: its error is of the size of f32 rounding itself."""
+def test_split_f16_kernel_is_f32_accurate(gpu_device):
+    """The split-f16 kernel (two round-to-nearest f16 pieces per f32 operand, 3 of the 4 partial products) against the
+    exact-f32 kernel and against the modules evaluated in f64: its error is of the size of f32 rounding itself -- also with
+    trained-size weights (x20) and with weights so small that their second pieces are f16 subnormals (x1e-3)."""
     import torch
     from ddpg_trucktrailer_amd import fused
     actor, critic = _nets(gpu_device, seed=11)
@@ -67,6 +68,17 @@ def test_split_bf16_kernel_is_f32_accurate(gpu_device):
     err_s, err_e, err_t = ((x - mu64).abs().max().item() for x in (mu_s, mu_e, mu_t))
     assert err_s <= 3 * max(err_e, err_t) + 1e-7, (err_s, err_e, err_t)
     assert (q_s - q64).abs().max().item() <= 3 * (q_e - q64).abs().max().item() + 1e-6
+    for scale in (20.0, 1e-3):
+        with torch.no_grad():
+            actor.fc2.weight.mul_(scale); actor.fc1.weight.mul_(scale)
+            mu64 = actor.double()(obs.double()).float(); actor.float()
+        mu_s = fused.actor_forward(actor, obs).clone()
+        with fused.exact_f32(actor):
+            mu_e = fused.actor_forward(actor, obs).clone()
+        assert torch.isfinite(mu_s).all()
+        assert (mu_s - mu64).abs().max().item() <= 3 * (mu_e - mu64).abs().max().item() + 2e-7, scale
+        with torch.no_grad():
+            actor.fc2.weight.div_(scale); actor.fc1.weight.div_(scale)
 
 
 def test_real_observations_and_weight_updates_are_seen(gpu_device):
