@@ -63,6 +63,15 @@ class TTSideBuffer(C.Structure):
                 ("count", C.c_int32), ("reserved_", C.c_int32)]
 
 
+class TTRingView(C.Structure):
+    _fields_ = [("cursor", C.c_void_p), ("obs", C.c_void_p), ("act", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p),
+                ("n_envs", C.c_int32), ("slots", C.c_int32)]
+
+
+class TTRingCursor(C.Structure):
+    _fields_ = [("k_dev", C.c_void_p), ("slots", C.c_int32), ("reserved_", C.c_int32), ("cursor", C.c_void_p)]
+
+
 class TTSampleArgs(C.Structure):
     _fields_ = [("batch", C.c_int32), ("n_envs", C.c_int32), ("slots", C.c_int32), ("reserve", C.c_int32), ("k_dev", C.c_void_p),
                 ("obs", C.c_void_p), ("act", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p), ("seed", C.c_uint64),
@@ -105,8 +114,11 @@ _SIGNATURES = {
     "tt_env_profile": (C.c_int, [_P, _I]),
     "tt_env_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "tt_mlp_split_ws_bytes": (C.c_uint64, []),
-    "tt_mlp_split_pack": (C.c_int, [C.POINTER(TTMlpWeights), _I, _P, _P, _P]),
-    "tt_mlp_split_pack_and_sample": (C.c_int, [C.POINTER(TTMlpWeights), _I, _P, C.POINTER(TTSampleArgs), _P]),
+    "tt_mlp_split_pack": (C.c_int, [C.POINTER(TTMlpWeights), _I, _P, _P, C.POINTER(TTRingCursor), _P]),
+    "tt_mlp_split_pack_and_sample": (C.c_int, [C.POINTER(TTMlpWeights), _I, _P, C.POINTER(TTSampleArgs), C.POINTER(TTRingCursor), _P]),
+    "tt_actor_act_ring": (C.c_int, [_I, C.POINTER(TTRingView), C.POINTER(TTMlpWeights), _P, _U64, _U64, _P, C.c_float, C.c_float,
+                                    C.c_float, _P, _P]),
+    "tt_env_step_ring": (C.c_int, [_P, _P, C.POINTER(TTRingView), _I, _P]),
     "tt_actor_forward": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_actor_act": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P, _U64, _U64, _P, C.c_float, C.c_float, C.c_float,
                                _P, _P, _P, _P]),

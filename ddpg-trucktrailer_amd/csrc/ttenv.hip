@@ -627,8 +627,13 @@ __global__ __launch_bounds__(BLOCK) void k_step(const KParams P, const int n, co
                                                 const float *__restrict__ action, float *__restrict__ action_out,
                                                 float *__restrict__ obs, float *__restrict__ reward,
                                                 uint8_t *__restrict__ done, const Info info, const uint64_t seed,
-                                                const uint64_t policy_seed) {
+                                                const uint64_t policy_seed, const int *__restrict__ cursor) {
     __shared__ __attribute__((aligned(16))) float tile[BLOCK * OBS];
+    if (cursor) {       // ring addressing (tt_env_step_ring): obs / reward / done are the ring's bases, the slots come from the cursor
+        obs += (size_t)cursor[1] * n * OBS;
+        reward += (size_t)cursor[0] * n;
+        done += (size_t)cursor[0] * n;
+    }
     const int block_first = blockIdx.x * BLOCK;
     const int i = block_first + threadIdx.x;
     const bool valid = i < n;
@@ -943,7 +948,7 @@ inline int grid_for(int n) { return (n + BLOCK - 1) / BLOCK; }
 
 template <bool PER_ENV, bool INFO, bool RANDOM_POLICY>
 void launch_step(tt_env *e, bool auto_reset, const float *action, float *action_out, float *obs, float *reward,
-                 uint8_t *done, const Info &info, uint64_t policy_seed, hipStream_t s) {
+                 uint8_t *done, const Info &info, uint64_t policy_seed, hipStream_t s, const int *cursor = nullptr) {
     const dim3 g(grid_for(e->n)), b(BLOCK);
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (e->profiling && e->ev_used < e->ev_start.size()) {
@@ -954,15 +959,15 @@ void launch_step(tt_env *e, bool auto_reset, const float *action, float *action_
     // hipExtLaunchKernelGGL with null events is a plain launch; with events they time this dispatch alone
     if (auto_reset)
         hipExtLaunchKernelGGL((k_step<PER_ENV, INFO, true, RANDOM_POLICY>), g, b, 0, s, t0, t1, 0, e->kp, e->n, e->b,
-                              action, action_out, obs, reward, done, info, e->seed, policy_seed);
+                              action, action_out, obs, reward, done, info, e->seed, policy_seed, cursor);
     else
         hipExtLaunchKernelGGL((k_step<PER_ENV, INFO, false, RANDOM_POLICY>), g, b, 0, s, t0, t1, 0, e->kp, e->n, e->b,
-                              action, action_out, obs, reward, done, info, e->seed, policy_seed);
+                              action, action_out, obs, reward, done, info, e->seed, policy_seed, cursor);
 }
 
 template <bool RANDOM_POLICY>
 int step_common(tt_env *env, const float *action, float *action_out, float *obs, float *reward, uint8_t *done,
-                const tt_info *info, int auto_reset, uint64_t policy_seed, hipStream_t stream) {
+                const tt_info *info, int auto_reset, uint64_t policy_seed, hipStream_t stream, const int *cursor = nullptr) {
     Info ki{nullptr, nullptr, nullptr};
     bool want_info = false;
     if (info) {
@@ -971,11 +976,11 @@ int step_common(tt_env *env, const float *action, float *action_out, float *obs,
     }
     const bool ar = auto_reset != 0;
     if (env->per_env) {
-        if (want_info) launch_step<true, true, RANDOM_POLICY>(env, ar, action, action_out, obs, reward, done, ki, policy_seed, stream);
-        else launch_step<true, false, RANDOM_POLICY>(env, ar, action, action_out, obs, reward, done, ki, policy_seed, stream);
+        if (want_info) launch_step<true, true, RANDOM_POLICY>(env, ar, action, action_out, obs, reward, done, ki, policy_seed, stream, cursor);
+        else launch_step<true, false, RANDOM_POLICY>(env, ar, action, action_out, obs, reward, done, ki, policy_seed, stream, cursor);
     } else {
-        if (want_info) launch_step<false, true, RANDOM_POLICY>(env, ar, action, action_out, obs, reward, done, ki, policy_seed, stream);
-        else launch_step<false, false, RANDOM_POLICY>(env, ar, action, action_out, obs, reward, done, ki, policy_seed, stream);
+        if (want_info) launch_step<false, true, RANDOM_POLICY>(env, ar, action, action_out, obs, reward, done, ki, policy_seed, stream, cursor);
+        else launch_step<false, false, RANDOM_POLICY>(env, ar, action, action_out, obs, reward, done, ki, policy_seed, stream, cursor);
     }
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(env, TT_EHIP, "tt_env_step launch: %s", hipGetErrorString(err));
@@ -1207,6 +1212,14 @@ int tt_env_step(tt_env *env, const float *action, float *obs, float *reward, uin
         return fail(env, TT_EINVAL, "tt_env_step: action, obs, reward and done are required");
     TT_HIP(env, hipSetDevice(env->device));
     return step_common<false>(env, action, nullptr, obs, reward, done, info, auto_reset, 0, stream);
+}
+
+int tt_env_step_ring(tt_env *env, const float *action, const tt_ring_view *ring, int auto_reset, tt_stream_t stream) {
+    if (!env) return fail(nullptr, TT_EINVAL, "tt_env_step_ring: NULL handle");
+    if (!action || !ring || !ring->cursor || !ring->obs || !ring->rew || !ring->done || ring->n_envs != env->n)
+        return fail(env, TT_EINVAL, "tt_env_step_ring: action and a ring view of this handle's %d envs are required", env->n);
+    TT_HIP(env, hipSetDevice(env->device));
+    return step_common<false>(env, action, nullptr, ring->obs, ring->rew, ring->done, nullptr, auto_reset, 0, stream, ring->cursor);
 }
 
 int tt_env_step_random(tt_env *env, uint64_t policy_seed, float *action_out, float *obs, float *reward, uint8_t *done,

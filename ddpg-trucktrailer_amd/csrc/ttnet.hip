@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_forward_v2(const int n, const fl
 #pragma unroll
         for (int ks = 0; ks < INP / 4; ++ks) {
             const int k = ks * 4 + l4;
-            a[ks] = (k < IN && wrow0 + l15 < n) ? obs[(size_t)(wrow0 + l15) * IN + k] : 0.f;
+            a[ks] = (k < IN && wrow0 + l15 < n) ? resolve_obs(act, obs)[(size_t)(wrow0 + l15) * IN + k] : 0.f;
         }
         __syncthreads();                     // staged weights visible
 #pragma unroll
@@ -261,7 +261,7 @@ int launch(int n, const float *obs, const float *action, const tt_mlp_weights *w
            hipStream_t stream) {
     if (use_split(n, w)) {
         // ws_packed: the caller keeps the image current itself (tt_mlp_split_pack after every weight update)
-        const int rc = w->ws_packed ? TT_OK : split_pack(w, CRITIC, w->split_ws, nullptr, stream);
+        const int rc = w->ws_packed ? TT_OK : split_pack(w, CRITIC, w->split_ws, nullptr, RingCursor{nullptr, 0, nullptr}, stream);
         return rc != TT_OK ? rc : split_forward(CRITIC, n, obs, action, w, out, act, stream);
     }
     static bool attr2[64] = {};     // per device
@@ -293,11 +293,16 @@ int tt_debug_bstamps(unsigned long long *out, int nblocks) { return ttnet::split
 
 uint64_t tt_mlp_split_ws_bytes(void) { return (uint64_t)split_ws_bytes(); }
 
-int tt_mlp_split_pack(const tt_mlp_weights *w, int critic, void *ws, int64_t *bump, tt_stream_t stream) {
-    if (!ws || !check_ptrs(w, critic != 0)) return TT_EINVAL;
-    return split_pack(w, critic != 0, ws, reinterpret_cast<long long *>(bump), stream);
+static RingCursor to_cursor(const tt_ring_cursor *c) {
+    return (c && c->cursor && c->k_dev && c->slots > 0)
+               ? RingCursor{reinterpret_cast<const long long *>(c->k_dev), c->slots, c->cursor} : RingCursor{nullptr, 0, nullptr};
 }
 
+int tt_mlp_split_pack(const tt_mlp_weights *w, int critic, void *ws, int64_t *bump, const tt_ring_cursor *cursor,
+                      tt_stream_t stream) {
+    if (!ws || !check_ptrs(w, critic != 0)) return TT_EINVAL;
+    return split_pack(w, critic != 0, ws, reinterpret_cast<long long *>(bump), to_cursor(cursor), stream);
+}
 
 int tt_actor_forward(int n, const float *obs, const tt_mlp_weights *w, float *mu_out, tt_stream_t stream) {
     if (n < 0 || !obs || !mu_out || !check_ptrs(w, false)) return TT_EINVAL;
@@ -336,6 +341,21 @@ static int make_sample(int batch, int n_envs, int slots, const int64_t *k_dev, c
     return TT_OK;
 }
 
+int tt_actor_act_ring(int n, const tt_ring_view *ring, const tt_mlp_weights *w, float *ou_state, uint64_t seed, uint64_t step,
+                      const int64_t *step_dev, float theta_dt, float sigma_sqrt_dt, float high, float *act_scaled_out,
+                      tt_stream_t stream) {
+    if (n <= 0 || !ring || !ring->cursor || !ring->obs || !ring->act || !ring->done || ring->n_envs != n || !ou_state ||
+        !act_scaled_out || !check_ptrs(w, false) || !w->split_ws || !w->ws_packed)
+        return TT_EINVAL;          // (ring addressing goes with a caller-kept image: the pack launch writes the cursor)
+    ActArgs act{};
+    act.ou = ou_state; act.done_prev = ring->done; act.act_raw = ring->act; act.act_scaled = act_scaled_out;
+    act.step_dev = reinterpret_cast<const long long *>(step_dev);
+    act.seed = seed; act.step = step;
+    act.decay = 1.0f - theta_dt; act.scale = sigma_sqrt_dt; act.high = high;
+    act.cursor = ring->cursor; act.ring_n = n;
+    return launch<false>(n, ring->obs, nullptr, w, nullptr, act, stream);
+}
+
 int tt_ring_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const float *obs, const float *act,
                    const float *rew, const uint8_t *done, uint64_t seed, int reserve, const tt_side_buffer *side, float *s_out,
                    float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out, tt_stream_t stream) {
@@ -347,13 +367,14 @@ int tt_ring_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 
-int tt_mlp_split_pack_and_sample(const tt_mlp_weights *w, int critic, void *ws, const tt_sample_args *a, tt_stream_t stream) {
+int tt_mlp_split_pack_and_sample(const tt_mlp_weights *w, int critic, void *ws, const tt_sample_args *a,
+                                 const tt_ring_cursor *cursor, tt_stream_t stream) {
     if (!ws || !a || !check_ptrs(w, critic != 0)) return TT_EINVAL;
     RingSample R;
     const int rc = make_sample(a->batch, a->n_envs, a->slots, a->k_dev, a->obs, a->act, a->rew, a->done, a->seed, a->reserve,
                                a->side, a->s_out, a->a_out, a->r_out, a->s2_out, a->d_out, a->idx_out, R);
     if (rc != TT_OK) return rc;
-    return split_pack_and_sample(w, critic != 0, ws, R, stream);
+    return split_pack_and_sample(w, critic != 0, ws, R, to_cursor(cursor), stream);
 }
 
 int tt_critic_forward(int n, const float *obs, const float *action, const tt_mlp_weights *w, float *q_out,

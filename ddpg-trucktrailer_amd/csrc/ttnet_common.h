@@ -27,7 +27,17 @@ struct ActArgs {                        // optional fused choose_action epilogue
     const long long *step_dev;          // device step counter (graph-safe) or NULL
     unsigned long long seed, step;
     float decay, scale, high;           // 1 - theta*dt, sigma*sqrt(dt), action_space.high
+    // Optional ring addressing (tt_actor_act_ring): obs / act_raw / done_prev are then the BASES of the trajectory ring's
+    // obs [slots,n,23], act [slots,n], done [slots,n] and the slot comes from the device cursor {t, t+1, t-1, t > 0} that the
+    // step's opening pack launch wrote -- so one captured launch serves every ring position
+    const int *cursor;
+    int ring_n;
 };
+
+// obs rows of this forward: the pointer itself, or slot cursor[0] of the ring
+__device__ __forceinline__ const float *resolve_obs(const ActArgs &act, const float *obs) {
+    return act.cursor ? obs + (size_t)act.cursor[0] * act.ring_n * IN : obs;
+}
 
 __device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                   uint32_t out[4]) {
@@ -57,7 +67,13 @@ __device__ __forceinline__ void finish_row(const int row, const float v, float *
     if (out) out[row] = mu;
     if (act.ou) {
         float x = act.ou[row];
-        if (act.done_prev && act.done_prev[row]) x = 0.f;
+        const uint8_t *done_prev = act.done_prev;
+        float *act_raw = act.act_raw;
+        if (act.cursor) {
+            done_prev = act.cursor[3] ? act.done_prev + (size_t)act.cursor[2] * act.ring_n : nullptr;
+            act_raw += (size_t)act.cursor[0] * act.ring_n;
+        }
+        if (done_prev && done_prev[row]) x = 0.f;
         const unsigned long long st = act.step + (act.step_dev ? (unsigned long long)*act.step_dev : 0ull);
         uint32_t rnd[4];
         philox4x32((uint32_t)row, (uint32_t)st, (uint32_t)(st >> 32), 0x0A5Eu, (uint32_t)act.seed,
@@ -68,7 +84,7 @@ __device__ __forceinline__ void finish_row(const int row, const float v, float *
         x = fmaf(x, act.decay, act.scale * nrm);
         act.ou[row] = x;
         const float a = mu + x;
-        act.act_raw[row] = a;
+        act_raw[row] = a;
         act.act_scaled[row] = fminf(fmaxf(a, -1.f), 1.f) * act.high;
     }
 }
@@ -141,10 +157,26 @@ inline Weights to_weights(const tt_mlp_weights *w) {
     return Weights{w->w1, w->b1, w->g1, w->be1, w->w2, w->b2, w->g2, w->be2, w->w3, w->b3, w->wa, w->ba};
 }
 
+// what the opening pack launch of a vector step writes for the step's other launches: {t, t+1, t-1, t > 0} (mod slots)
+struct RingCursor {
+    const long long *k_dev;
+    int slots;
+    int *cursor;
+};
+__device__ __forceinline__ void write_cursor(const RingCursor &c) {
+    if (!c.cursor) return;
+    const long long k = *c.k_dev;
+    c.cursor[0] = (int)(k % c.slots);
+    c.cursor[1] = (int)((k + 1) % c.slots);
+    c.cursor[2] = (int)((k + c.slots - 1) % c.slots);
+    c.cursor[3] = k > 0 ? 1 : 0;
+}
+
 // csrc/ttnet_split.hip
 size_t split_ws_bytes();
-int split_pack(const tt_mlp_weights *w, bool critic, void *ws, long long *bump, hipStream_t stream);
-int split_pack_and_sample(const tt_mlp_weights *w, bool critic, void *ws, const RingSample &R, hipStream_t stream);
+int split_pack(const tt_mlp_weights *w, bool critic, void *ws, long long *bump, const RingCursor &cur, hipStream_t stream);
+int split_pack_and_sample(const tt_mlp_weights *w, bool critic, void *ws, const RingSample &R, const RingCursor &cur,
+                          hipStream_t stream);
 int split_forward(bool critic, int n, const float *obs, const float *action, const tt_mlp_weights *w, float *out,
                   const ActArgs &act, hipStream_t stream);
 #ifdef TT_STAMPS

@@ -103,8 +103,11 @@ __device__ __forceinline__ f32x16 mfma_f16(const uint4 a, const uint4 b, const f
 //     carries the bias, the observation operand carries a 1 there);
 //   vec: g1*SX | be1*SX [2][416], b2 | g2 | be2 | w3 | wa | ba [6][320], zero beyond the real neurons; then b3.
 __device__ __forceinline__ void split_pack_body(const Weights &W, const bool critic, unsigned char *__restrict__ ws,
-                                                long long *__restrict__ bump, const int idx) {
-    if (bump && idx == 0) *bump += 1;      // optional step counter of a pipelined loop (read by LATER launches only)
+                                                long long *__restrict__ bump, const RingCursor &cur, const int idx) {
+    if (idx == 0) {
+        if (bump) *bump += 1;              // optional step counter of a pipelined loop (read by LATER launches only)
+        write_cursor(cur);                 // ring slots of the step this launch opens (nothing advances k_dev right now)
+    }
     constexpr int N2 = STEPS * T2 * 64, N1 = S1 * T1 * 64;
     if (idx < N2 + N1) {
         const bool l2 = idx < N2;
@@ -156,17 +159,17 @@ constexpr int PACK_THREADS = (STEPS * T2 + S1 * T1) * 64 + VEC_BYTES / 4;
 constexpr int PACK_BLOCKS = (PACK_THREADS + 255) / 256;
 
 __global__ __launch_bounds__(256) void k_split_pack(const Weights W, const bool critic, unsigned char *__restrict__ ws,
-                                                    long long *__restrict__ bump) {
-    split_pack_body(W, critic, ws, bump, blockIdx.x * 256 + threadIdx.x);
+                                                    long long *__restrict__ bump, const RingCursor cur) {
+    split_pack_body(W, critic, ws, bump, cur, blockIdx.x * 256 + threadIdx.x);
 }
 
 // What opens a pipelined vector step, in ONE launch (two small kernels would each cost their ~4 us of launch and a
 // dependency gap on the loop's critical path): the policy's image from the actor's current weights, and the first batch of
 // this step's learn() from the replay ring (four sampled transitions per 256-thread workgroup).
 __global__ __launch_bounds__(256) void k_pack_and_sample(const Weights W, const bool critic, unsigned char *__restrict__ ws,
-                                                         const RingSample R) {
+                                                         const RingSample R, const RingCursor cur) {
     if ((int)blockIdx.x < PACK_BLOCKS) {
-        split_pack_body(W, critic, ws, nullptr, blockIdx.x * 256 + threadIdx.x);
+        split_pack_body(W, critic, ws, nullptr, cur, blockIdx.x * 256 + threadIdx.x);
         return;
     }
     const int b = ((int)blockIdx.x - PACK_BLOCKS) * 4 + (threadIdx.x >> 6);
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     float xo[S1][8];                                                          // obs^T as the B operand: input 16 s + 8 h + j
     // unconditional loads from clamped (always valid) addresses, selected afterwards: 16 loads in flight at once
     // instead of 16 exec-masked round trips
-    const float *orow = obs + (size_t)(row < n ? row : n - 1) * IN;
+    const float *orow = resolve_obs(act, obs) + (size_t)(row < n ? row : n - 1) * IN;
 #pragma unroll
     for (int s = 0; s < S1; ++s)
 #pragma unroll
@@ -432,15 +435,16 @@ int split_debug_block_stamps(unsigned long long *out, int nblocks) {
 
 size_t split_ws_bytes() { return (size_t)WS_BYTES; }
 
-int split_pack(const tt_mlp_weights *w, bool critic, void *ws, long long *bump, hipStream_t stream) {
+int split_pack(const tt_mlp_weights *w, bool critic, void *ws, long long *bump, const RingCursor &cur, hipStream_t stream) {
     hipLaunchKernelGGL(k_split_pack, dim3(PACK_BLOCKS), dim3(256), 0, stream, to_weights(w), critic,
-                       reinterpret_cast<unsigned char *>(ws), bump);
+                       reinterpret_cast<unsigned char *>(ws), bump, cur);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 
-int split_pack_and_sample(const tt_mlp_weights *w, bool critic, void *ws, const RingSample &R, hipStream_t stream) {
+int split_pack_and_sample(const tt_mlp_weights *w, bool critic, void *ws, const RingSample &R, const RingCursor &cur,
+                          hipStream_t stream) {
     hipLaunchKernelGGL(k_pack_and_sample, dim3(PACK_BLOCKS + (R.batch + 3) / 4), dim3(256), 0, stream, to_weights(w), critic,
-                       reinterpret_cast<unsigned char *>(ws), R);
+                       reinterpret_cast<unsigned char *>(ws), R, cur);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 

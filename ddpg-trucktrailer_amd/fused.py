@@ -22,13 +22,26 @@ def supported(net):
             and tuple(net.fc2.weight.shape) == (300, 400) and net.bn1.eps == 1e-5 and net.bn2.eps == 1e-5)
 
 
-def pack_and_sample(net, index, sample_args):
+def pack_and_sample(net, index, sample_args, cursor=None):
     """pack() and the replay draw described by `sample_args` (TrajectoryRing.sample_args) in ONE launch
-    (tt_mlp_split_pack_and_sample): what opens a pipelined vector step."""
+    (tt_mlp_split_pack_and_sample): what opens a pipelined vector step.  cursor: TrajectoryRing.cursor() or None."""
     w = packed_weights_of(net, index)
     dev = net.fc2.weight.device
     L.check(L.load().tt_mlp_split_pack_and_sample(C.byref(w), 1 if hasattr(net, "action_value") else 0, C.c_void_p(w.split_ws),
-                                                  C.byref(sample_args), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+                                                  C.byref(sample_args), C.byref(cursor) if cursor is not None else None,
+                                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+
+
+def actor_act_ring(net, ring_view, weights, ou_state, act_scaled, seed, step=0, step_dev=None, theta=0.2, sigma=0.15, dt=1e-2,
+                   high=math.pi / 4):
+    """actor_act on the ring slot the device cursor names (tt_actor_act_ring): observations from slot t, stored action
+    into slot t, noise restarted where slot t-1 says done."""
+    dev = net.fc2.weight.device
+    L.check(L.load().tt_actor_act_ring(int(ring_view.n_envs), C.byref(ring_view), C.byref(weights), _ptr(ou_state),
+                                       int(seed) & (2 ** 64 - 1), int(step), _ptr(step_dev), float(theta * dt),
+                                       float(sigma * math.sqrt(dt)), float(high), _ptr(act_scaled),
+                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return act_scaled
 
 
 def _fill_weights(net, w):
@@ -76,13 +89,15 @@ def packed_weights_of(net, index, max_workgroups=None):
     return hit[1]
 
 
-def pack(net, index, bump=None):
+def pack(net, index, bump=None, cursor=None):
     """Write the split kernel's image of `net`'s CURRENT weights into its workspace `index` (tt_mlp_split_pack);
-    bump: device int64 scalar incremented by the launch (a pipelined loop's step counter) or None."""
+    bump: device int64 scalar incremented by the launch or None; cursor: TrajectoryRing.cursor() -- the launch then also
+    writes the ring slots of the vector step it opens."""
     w = packed_weights_of(net, index)
     dev = net.fc2.weight.device
     L.check(L.load().tt_mlp_split_pack(C.byref(w), 1 if hasattr(net, "action_value") else 0, C.c_void_p(w.split_ws),
-                                       _ptr(bump), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+                                       _ptr(bump), C.byref(cursor) if cursor is not None else None,
+                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 
 
 @contextlib.contextmanager
@@ -132,7 +147,7 @@ def actor_act(net, obs, ou_state, act_raw, act_scaled, seed, step=0, step_dev=No
 def policy_kernel_info(n):
     """What the N-env policy forward executes on the matrix cores, for bench.py's roofline_mfma object."""
     waves = 4 * ((n + 127) // 128)
-    return {"kernel": "k_split_pack + k_mlp_split (choose_action for N envs; split-f16)",
+    return {"kernel": "k_mlp_split (choose_action for N envs; split-f16; the image's pack launch, ~4 us per step, not included)",
             # v_mfma_f32_32x32x16_f16, 32768 FLOP each: layer 2 = 25 k16 steps x 10 tiles x 3 products, layer 1 = 2 x 13 x 3
             "mfma_flop": waves * (750 + 78) * 32768.0,
             "note": "f16 MFMA FLOP executed (three f16 products per f32 product block, both layers) over the dense f16/bf16 "

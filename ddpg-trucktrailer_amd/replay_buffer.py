@@ -71,6 +71,9 @@ class TrajectoryRing:
         self.side = None
         self.side_count = 0
         self.side_epoch = 0
+        # {t, t+1, t-1, t > 0}: ring slots of the running vector step, written on the device by the step's opening launch
+        # (include/ttenv.h: tt_ring_view / tt_ring_cursor) so that captured launches need no per-position pointers
+        self.cursor_dev = torch.zeros(4, dtype=torch.int32, device=device)
 
     def attach(self, env):
         """Let the env's step kernel advance k_dev (tt_env_set_step_counter): one launch less per vector step.  From
@@ -152,6 +155,15 @@ class TrajectoryRing:
                 self.side_epoch += 1
         self.k = int(sd["k"])               # the counters come back whether or not the contents did
         self.k_dev.fill_(self.k)
+
+    def view(self):
+        from ddpg_trucktrailer_amd import _lib as L
+        return L.TTRingView(self.cursor_dev.data_ptr(), self.obs.data_ptr(), self.act.data_ptr(), self.rew.data_ptr(),
+                            self.done.data_ptr(), self.n, self.slots)
+
+    def cursor(self):
+        from ddpg_trucktrailer_amd import _lib as L
+        return L.TTRingCursor(self.k_dev.data_ptr(), self.slots, 0, self.cursor_dev.data_ptr())
 
     def _batch_bufs(self, batch_size):
         if getattr(self, "_bufs", None) is None or self._bufs[0].shape[0] != batch_size:

@@ -7,11 +7,10 @@ Per vector step, for all N envs of this rank at once:
     remember(obs, a, r, obs', done)                (a = the UNCLIPPED noisy action, trainv2.py:525):
                                                    obs', r, done are written by the kernel straight into the ring
     learn() x updates_per_step                     (gradient steps, each on a fresh batch from the ring)
-Everything stays on the device.  run(k) replays hipGraphs of whole vector steps (policy, env step and learn(): about ten
-launches per step, back to back with no host in between): graphs of `graph_steps` steps where the ring position allows
-it, single-step graphs for every other position, so that no step of a run() is launched eagerly whatever k and the
-position are.  step() is the same vector step launched eagerly, with learn() alone captured (sampling included).  All of
-them give the same bits.
+Everything stays on the device.  run(k) replays hipGraphs of whole vector steps (policy, env step and learn(): seven to
+nine launches per step with no host in between): ONE graph of `graph_steps` steps and ONE single-step graph serve every
+ring position (the launches find the step's ring slots through a device cursor), so that no step of a run() is launched
+eagerly whatever k and the position are.  step() is the same vector step launched eagerly.  All of them give the same bits.
 
 Data-parallel ranks (one process per GPU): a step is three graph segments with the two gradient all-reduces of
 DDPG_agent.py:95-104 between them, launched eagerly on RCCL (the collectives are not captured).
@@ -42,7 +41,6 @@ from ddpg_trucktrailer_amd.replay_buffer import TrajectoryRing
 # collective library's watchdog, a data loader) from invalidating it
 _CAPTURE_MODE = "thread_local"
 _SEED_STRIDE = 0x9E3779B97F4A7C15     # sampling key of update u of a vector step = seed + u * stride (mod 2^64)
-_MAX_GRAPH_SLOTS = 1024               # whole-step graphs exist per ring position: not for rings of a million slots
 
 
 class DDPGRollout:
@@ -104,15 +102,17 @@ class DDPGRollout:
         if self.pipeline:
             self._pipe_side = torch.cuda.Stream(device=self.device)
         self.vector_steps = 0
-        # whole-step graphs: the ring slots a step touches depend on k mod slots only, so a graph of G steps captured at
-        # ring position c*G is valid whenever k = c*G (mod slots): slots/G graphs cover the cycle, and one single-step
-        # graph per position covers everything else (unaligned starts, remainders)
-        ok = self.use_graph and self.learner is not None and graph_steps and replay_slots <= _MAX_GRAPH_SLOTS
+        # ring addressing: the policy and env launches find the step's ring slots through a device cursor that the step's
+        # opening pack launch writes (include/ttenv.h: tt_ring_view), not through per-slot pointers -- so ONE captured
+        # graph serves every ring position: a single-step graph and a graph of `graph_steps` steps are all there is
+        self.ring_mode = self.fused_act and self.device.type == "cuda" and self.ring._env_counts
+        self._view = self.ring.view() if self.ring_mode else None
+        ok = self.use_graph and self.learner is not None and graph_steps and self.ring_mode
         self.graph_steps = int(graph_steps) if ok else 0
-        if self.graph_steps and (replay_slots % self.graph_steps or self.dp):
+        if self.graph_steps and self.dp:
             self.graph_steps = 1        # data-parallel: a step is three graphs with the two gradient all-reduces between
-        self.step_graphs = None         # [slots / G] graphs of G steps (G > 1, one rank)
-        self.step_graphs1 = None        # [slots] single-step graphs (data-parallel: up to the critic's gradient)
+        self.graph1 = None              # one vector step (data-parallel: up to the critic's gradient)
+        self.graphG = None              # graph_steps vector steps (one rank)
         self.dp_graphs = None
         self._graph_epoch = None        # env.graph_epoch the captures were made under
 
@@ -195,8 +195,28 @@ class DDPGRollout:
         self.graph.replay()
 
     # -------------------------------------------------------------- one vector step
-    def _act_and_step(self, k):
-        """The policy + env launches of vector step number k (k selects the ring slots; everything else is on the device)."""
+    def _open_step(self, learn):
+        """The launch that opens a vector step: the policy's image from the actor's current weights and the ring cursor of
+        the step -- in the pipelined order also the first batch of the step's learn()."""
+        if self.pipeline and learn:
+            fused.pack_and_sample(self.agent.actor, 0, self.ring.sample_args(
+                self.batch_size, seed=self._sample_key(0), k_dev=self.k_pipe_dev, reserve=1), cursor=self.ring.cursor())
+        else:
+            fused.pack(self.agent.actor, 0, cursor=self.ring.cursor())
+
+    def policy_launch(self):
+        """The policy launch of the running step alone (ring mode; after _open_step): bench.py times it."""
+        w = fused.packed_weights_of(self.agent.actor, 0, self.policy_workgroups if self.pipeline else 0)
+        return fused.actor_act_ring(self.agent.actor, self._view, w, self.noise.x, self.scaled, seed=self.seed, step=0,
+                                    step_dev=self.ring.k_dev, high=self.high)
+
+    def _act_and_step(self, k=None):
+        """The policy + env launches of the running vector step.  Ring mode: everything that selects the slots is on the
+        device (after _open_step).  Otherwise (CPU, torch actor) k selects them."""
+        if self.ring_mode:
+            self.policy_launch()
+            self.env.step_ring(self.scaled, self._view, auto_reset=True)
+            return
         ring = self.ring
         t, t1 = ring.slot(k), ring.slot(k + 1)
         # the noise of an env whose episode ended at the previous step restarts at 0 (trainv2.py:492)
@@ -205,7 +225,7 @@ class DDPGRollout:
         self.env.step(scaled, auto_reset=True, obs_out=ring.obs[t1], reward_out=ring.rew[t], done_out=ring.done[t])
 
     def _pipelined(self, k, learn, dp_capture=False):
-        """Vector step k in the pipelined order, on the current stream and the side stream:
+        """The running vector step (number k) in the pipelined order, on the current stream and the side stream:
             current:  pack the policy's image from the actor as learn() of step k-1 left it; then, beside each other,
             side:     learn(), whose last update moves the sampling window on      | current:  policy, env step
         joined at the end.  The same code runs under capture (two branches of one graph) and eagerly (two streams).  The
@@ -213,11 +233,7 @@ class DDPGRollout:
         it off learn()'s path) ROCm's graph executor runs the two branches one after the other (tools/graph_probe2.py).
         dp_capture: only learn()'s first segment (up to the critic's gradient) goes beside the policy; _dp_step does the rest."""
         cur, side = torch.cuda.current_stream(self.device), self._pipe_side
-        if learn:      # ... and the first batch of this step's learn(), in the same launch (one kernel and one gap less)
-            fused.pack_and_sample(self.agent.actor, 0, self.ring.sample_args(
-                self.batch_size, seed=self._sample_key(0), k_dev=self.k_pipe_dev, reserve=1))
-        else:
-            fused.pack(self.agent.actor, 0)
+        self._open_step(learn)     # image + cursor + (one kernel and one gap less) the first batch of this step's learn()
         side.wait_stream(cur)
         # learn()'s branch is recorded first: with the policy's launches first the step takes 0.131 ms instead of 0.120
         with torch.cuda.stream(side):
@@ -228,7 +244,7 @@ class DDPGRollout:
                 self._learn_all(presampled=True)
             else:
                 self.k_pipe_dev.add_(1)                     # no learn() yet: the window still moves with the steps
-        self._act_and_step(k)
+        self._act_and_step()
         cur.wait_stream(side)
 
     def step(self):
@@ -238,6 +254,8 @@ class DDPGRollout:
             self._pipelined(k, k >= 2)
             self.ring.advance()
         else:
+            if self.ring_mode:
+                self._open_step(False)
             self._act_and_step(k)
             self.ring.advance()
             self.learn()
@@ -248,7 +266,7 @@ class DDPGRollout:
         """Drop every captured graph (they bake kernel arguments by value: the env's reset seed, per-env-goal mode and
         pose pool, the ring's side-buffer count; ring and network addresses).  Called automatically when the env or the
         ring reports a change of those (env.graph_epoch, ring.side_epoch)."""
-        self.graph = self.step_graphs = self.step_graphs1 = self.dp_graphs = None
+        self.graph = self.graph1 = self.graphG = self.dp_graphs = None
 
     def _check_epoch(self):
         epoch = (getattr(self.env, "graph_epoch", 0), self.ring.side_epoch)
@@ -259,42 +277,34 @@ class DDPGRollout:
 
     def _graphs_current(self):
         self._check_epoch()
-        return self.step_graphs1 is not None
+        return self.graph1 is not None
 
-    def _capture_whole_step(self, k, side):
-        """One captured vector step at ring position k (mod slots); data-parallel: up to the critic's gradient."""
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side, capture_error_mode=_CAPTURE_MODE):
-            self._capture_body(k)
-        return g
-
-    def _capture_body(self, k):
-        kk = self.ring.slots + k                     # + slots: any k > 0 with this ring position (and parity: slots is even)
+    def _capture_body(self):
+        """One whole vector step (data-parallel: up to the critic's gradient; the rest in _dp_step)."""
         if self.pipeline:
-            # (data-parallel: up to the critic's gradient beside the policy; the rest in _dp_step)
-            self._pipelined(kk, True, dp_capture=self.dp)
+            self._pipelined(None, True, dp_capture=self.dp)
             return
-        self._act_and_step(kk)
+        self._open_step(False)
+        self._act_and_step()
         if self.dp:
             s, a, r, s2, d = self._sample(0)
             self.learner.phase_a(s, a, r, s2, d, fuse_adam=False)
         else:
             self._learn_all()
 
+    def _capture(self, fn, side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side, capture_error_mode=_CAPTURE_MODE):
+            fn()
+        return g
+
     def _capture_step_graphs(self):
         ring, G = self.ring, self.graph_steps
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         assert getattr(ring, "_bufs", None) is not None, "sample buffers must exist before a capture (run a step first)"
-        self.step_graphs1 = [self._capture_whole_step(pos, side) for pos in range(ring.slots)]
-        self.step_graphs = []
-        if G > 1:
-            for c in range(ring.slots // G):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side, capture_error_mode=_CAPTURE_MODE):
-                    for i in range(G):
-                        self._capture_body(c * G + i)
-                self.step_graphs.append(g)
+        self.graph1 = self._capture(self._capture_body, side)
+        self.graphG = self._capture(lambda: [self._capture_body() for _ in range(G)], side) if G > 1 else None
         if self.dp:
             s = ring._bufs[0]
             self.dp_graphs = {}
@@ -304,16 +314,13 @@ class DDPGRollout:
                 pieces[("a", u)] = (lambda u=u, last=last: self.learner.phase_a(
                     *self._sample(u), fuse_adam=False, window_dev=self.k_pipe_dev if last else None))
             for name, fn in pieces.items():
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side, capture_error_mode=_CAPTURE_MODE):
-                    fn()
-                self.dp_graphs[name] = g
+                self.dp_graphs[name] = self._capture(fn, side)
         torch.cuda.current_stream().wait_stream(side)
 
     def _dp_step(self):
         """One data-parallel vector step: three graph replays per update with the reference's two optimizer-site
         all-reduces (DDPG_agent.py:95-104) between them, launched eagerly on the flat gradient buffers."""
-        self.step_graphs1[self.ring.k % self.ring.slots].replay()
+        self.graph1.replay()
         for u in range(self.updates_per_step):
             if u:
                 self.dp_graphs[("a", u)].replay()
@@ -349,25 +356,24 @@ class DDPGRollout:
         steady-state steps only.  Advances the loop by 4 vector steps."""
         while self.ring.k < 4:
             self.step()
-        if self.graph_steps and self.ring._env_counts and not self._graphs_current():
+        if self.graph_steps and not self._graphs_current():
             self._try_capture()
 
     def run(self, k):
         """k vector steps, every one a graph replay once the loop is warm (4 eager steps) when whole-step graphs are on:
-        graphs of graph_steps steps at aligned ring positions, single-step graphs elsewhere; eager step() otherwise."""
+        the graph of graph_steps steps while that many remain, the single-step graph for the rest; eager step() otherwise."""
         ring = self.ring
         while k > 0:
             G = self.graph_steps
-            if G and ring.k >= 4 and ring._env_counts and (self._graphs_current() or self._try_capture()):
-                pos = ring.k % ring.slots
+            if G and ring.k >= 4 and (self._graphs_current() or self._try_capture()):
                 if self.dp:
                     self._dp_step()
                     done = 1
-                elif G > 1 and k >= G and pos % G == 0:
-                    self.step_graphs[pos // G].replay()
+                elif G > 1 and k >= G:
+                    self.graphG.replay()
                     done = G
                 else:
-                    self.step_graphs1[pos].replay()
+                    self.graph1.replay()
                     done = 1
                 ring.k += done                  # host mirror; the step kernels advanced k_dev
                 self.vector_steps += done

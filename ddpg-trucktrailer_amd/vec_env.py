@@ -197,6 +197,11 @@ class TruckTrailerVecEnv:
                                          C.byref(ti) if ti is not None else None, 1 if auto_reset else 0, self._stream()))
         return obs, rew, done, inf
 
+    def step_ring(self, action, ring_view, auto_reset=True):
+        """step() with its outputs addressed through a trajectory ring's device cursor (tt_env_step_ring): obs into slot
+        t+1, reward and done into slot t -- one captured launch serves every ring position."""
+        self._check(self.lib.tt_env_step_ring(self._h, _ptr(action), C.byref(ring_view), 1 if auto_reset else 0, self._stream()))
+
     def set_step_counter(self, counter):
         """counter: device int64 scalar tensor that every step launch advances by 1 (None detaches); see
         include/ttenv.h: tt_env_set_step_counter.  The tensor is kept alive by this object."""

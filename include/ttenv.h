@@ -158,6 +158,24 @@ int tt_env_set_step_counter(tt_env *env, int64_t *counter);
 int tt_env_step(tt_env *env, const float *action, float *obs, float *reward, uint8_t *done, const tt_info *info,
                 int auto_reset, tt_stream_t stream);
 
+/* Ring addressing: the trajectory ring of a rollout loop (obs [slots,N,23], act / rew [slots,N] f32, done [slots,N] u8) and a
+ * device cursor {t, t+1, t-1, t > 0} (slot numbers of the running vector step, written by the step's opening launch:
+ * tt_ring_cursor of tt_mlp_split_pack[_and_sample]).  Launches that take a view read / write the step's slots through the
+ * cursor instead of through per-slot pointers, so ONE captured hipGraph serves every ring position. */
+typedef struct tt_ring_view {
+    const int32_t *cursor;  /* [4] device */
+    float *obs, *act, *rew;
+    uint8_t *done;
+    int32_t n_envs, slots;
+} tt_ring_view;
+typedef struct tt_ring_cursor {
+    const int64_t *k_dev;   /* vector steps completed (tt_env_set_step_counter); nothing may advance it beside the launch */
+    int32_t slots, reserved_;
+    int32_t *cursor;        /* [4] device, written */
+} tt_ring_cursor;
+/* tt_env_step with obs -> ring slot t+1, reward and done -> slot t (env.step of the vector loop, trainv2.py:520-525). */
+int tt_env_step_ring(tt_env *env, const float *action, const tt_ring_view *ring, int auto_reset, tt_stream_t stream);
+
 /* tt_env_step with BASELINE.json config 2's "random policy" drawn inside the kernel:
  * action = U(-1,1) * pi/4 from Philox keyed by (policy_seed, env, step-in-episode, episode number), so no
  * host-side counter changes between launches and a captured hipGraph of K steps replays correctly.
@@ -213,7 +231,8 @@ uint64_t tt_mlp_split_ws_bytes(void);
 /* Write the split kernel's image of `w` (fc2 and fc1 as pre-split f16 fragments, per-neuron vectors, head bias) into ws
  * (tt_mlp_split_ws_bytes() bytes).  bump (may be NULL): a device int64 that this launch increments by one -- the step
  * counter of a pipelined loop whose learn() chain ends with this pack. */
-int tt_mlp_split_pack(const tt_mlp_weights *w, int critic, void *ws, int64_t *bump, tt_stream_t stream);
+int tt_mlp_split_pack(const tt_mlp_weights *w, int critic, void *ws, int64_t *bump, const tt_ring_cursor *cursor,
+                      tt_stream_t stream);   /* cursor (may be NULL): also writes the ring cursor of the step this launch opens */
 
 /* ActorNetwork.forward (DDPG/networks.py:138-147) for n rows: mu_out [n] = tanh(mu(...)). */
 int tt_actor_forward(int n, const float *obs /*[n,23]*/, const tt_mlp_weights *w, float *mu_out, tt_stream_t stream);
@@ -226,6 +245,12 @@ int tt_actor_forward(int n, const float *obs /*[n,23]*/, const tt_mlp_weights *w
 int tt_actor_act(int n, const float *obs, const tt_mlp_weights *w, float *ou_state, const uint8_t *done_prev,
                  uint64_t seed, uint64_t step, const int64_t *step_dev, float theta_dt, float sigma_sqrt_dt, float high,
                  float *mu_out, float *act_raw_out, float *act_scaled_out, tt_stream_t stream);
+
+/* tt_actor_act on ring slot t (observations in, stored actions out, done flags of slot t-1 restart the noise): `w` must carry a
+ * caller-kept image (ws_packed). */
+int tt_actor_act_ring(int n, const tt_ring_view *ring, const tt_mlp_weights *w, float *ou_state, uint64_t seed, uint64_t step,
+                      const int64_t *step_dev, float theta_dt, float sigma_sqrt_dt, float high, float *act_scaled_out,
+                      tt_stream_t stream);
 
 /* ReplayBuffer.sample_buffer (DDPG/replay_buffer.py:23-34: uniform WITH replacement) on the device trajectory ring
  * obs [slots,N,23] f32, act/rew [slots,N] f32, done [slots,N] u8 (transition (t,e) = obs[t][e], act[t][e], rew[t][e],
@@ -263,7 +288,8 @@ typedef struct tt_sample_args {
     uint8_t *d_out;
     int32_t *idx_out;
 } tt_sample_args;
-int tt_mlp_split_pack_and_sample(const tt_mlp_weights *w, int critic, void *ws, const tt_sample_args *sample, tt_stream_t stream);
+int tt_mlp_split_pack_and_sample(const tt_mlp_weights *w, int critic, void *ws, const tt_sample_args *sample,
+                                 const tt_ring_cursor *cursor, tt_stream_t stream);
 
 /* CriticNetwork.forward (DDPG/networks.py:55-68) for n rows: q_out [n]. */
 int tt_critic_forward(int n, const float *obs /*[n,23]*/, const float *action /*[n]*/, const tt_mlp_weights *w,

@@ -137,7 +137,7 @@ def _loop_worker(rank, world, port, out_dir):
         loop = DDPGRollout(env, batch_size=128, replay_slots=8, seed=27 + rank, world_size=world, graph_steps=graph_steps)
         loop.run(13)
         torch.cuda.synchronize()
-        assert (loop.step_graphs is not None) == (graph_steps > 0)
+        assert (loop.graph1 is not None) == (graph_steps > 0)
         flats.append(torch.cat([p.detach().reshape(-1) for net in loop.agent._nets() for p in net.parameters()]).cpu())
         env.close()
     torch.save(flats, os.path.join(out_dir, f"loop{rank}.pt"))
@@ -183,7 +183,7 @@ def _nccl_loop_worker(rank, world, port, out_dir):
         loop.run(13)
         torch.cuda.synchronize()
         if kw["graph_steps"]:
-            assert loop.step_graphs1 is not None and (loop.dp_graphs is not None) == loop.dp
+            assert loop.graph1 is not None and (loop.dp_graphs is not None) == loop.dp
         flats.append(torch.cat([p.detach().reshape(-1) for net in loop.agent._nets() for p in net.parameters()]).cpu())
         env.close()
     torch.save(flats, os.path.join(out_dir, f"nccl{rank}.pt"))
