@@ -295,12 +295,24 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
         // gamma*SX, beta*SX, ReLU, then straight into the two f16 pieces layer 2 multiplies with: hb[s] / mb[s] are the
         // B fragments (h, m planes) of k16 step s -- element j of lane half h is neuron 16 s + 8 (j >> 2) + 4 h + (j & 3),
         // i.e. registers 8 (s & 1) .. + 7 of tile s >> 1, the order the packed fc2 fragments are laid out in
-#pragma unroll
-        for (int t = 0; t < T1; ++t)
+        // The per-neuron vectors come from LDS a whole tile AHEAD of their use (8 ds_read_b128, pinned above the tile's
+        // arithmetic): a lone wave hides no latency, and read-then-use cost one exposed LDS round trip per group of four.
+        float4 gq[2][4], bq[2][4];
+        auto ld1 = [&](const int t, float4 (&g)[4], float4 (&be)[4]) {
 #pragma unroll
             for (int i = 0; i < (t == T1 - 1 ? 2 : 4); ++i) {
-                const float4 g = *reinterpret_cast<const float4 *>(p1_s + 32 * t + 8 * i + 4 * h);
-                const float4 be = *reinterpret_cast<const float4 *>(p1_s + H1P + 32 * t + 8 * i + 4 * h);
+                g[i] = *reinterpret_cast<const float4 *>(p1_s + 32 * t + 8 * i + 4 * h);
+                be[i] = *reinterpret_cast<const float4 *>(p1_s + H1P + 32 * t + 8 * i + 4 * h);
+            }
+        };
+        ld1(0, gq[0], bq[0]);
+#pragma unroll
+        for (int t = 0; t < T1; ++t) {
+            if (t + 1 < T1) ld1(t + 1, gq[(t + 1) & 1], bq[(t + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < (t == T1 - 1 ? 2 : 4); ++i) {
+                const float4 g = gq[t & 1][i], be = bq[t & 1][i];
                 const float y0 = fmaxf(fmaf(acc1[t][4 * i] * rstd, g.x, be.x), 0.f);
                 const float y1 = fmaxf(fmaf(acc1[t][4 * i + 1] * rstd, g.y, be.y), 0.f);
                 const float y2 = fmaxf(fmaf(acc1[t][4 * i + 2] * rstd, g.z, be.z), 0.f);
@@ -309,6 +321,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
                 split2(y0, y1, hb[st][e], mb[st][e]);
                 split2(y2, y3, hb[st][e + 1], mb[st][e + 1]);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     NSTAMP(3);
@@ -375,17 +389,29 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     NSTAMP(4);
     // ---- epilogue: scale back + bias, LayerNorm(300), (critic: + action_value(a)), ReLU, head; acc2[u][v] is neuron
     // 32u + 8(v>>2) + 4h + (v&3); 300 = 9*32 + 12, so groups of four are all real or all padding
+    // (the per-neuron vectors are read from LDS one tile ahead of their use, as in LayerNorm 1)
     float s2 = 0.f;
+    {
+        float4 bq[2][4];
+        auto ldb = [&](const int u, float4 (&b)[4]) {
 #pragma unroll
-    for (int u = 0; u < T2; ++u)
+            for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const float4 *>(p2_s + 32 * u + 8 * i + 4 * h);   // zero beyond 300
+        };
+        ldb(0, bq[0]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m0 = 32 * u + 8 * i + 4 * h;
-            const float4 b = *reinterpret_cast<const float4 *>(p2_s + m0);    // zero beyond 300 (so are the products)
-            acc2[u][4 * i] = fmaf(acc2[u][4 * i], UNSCALE, b.x); acc2[u][4 * i + 1] = fmaf(acc2[u][4 * i + 1], UNSCALE, b.y);
-            acc2[u][4 * i + 2] = fmaf(acc2[u][4 * i + 2], UNSCALE, b.z); acc2[u][4 * i + 3] = fmaf(acc2[u][4 * i + 3], UNSCALE, b.w);
-            s2 += (acc2[u][4 * i] + acc2[u][4 * i + 1]) + (acc2[u][4 * i + 2] + acc2[u][4 * i + 3]);
+        for (int u = 0; u < T2; ++u) {
+            if (u + 1 < T2) ldb(u + 1, bq[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 b = bq[u & 1][i];
+                acc2[u][4 * i] = fmaf(acc2[u][4 * i], UNSCALE, b.x); acc2[u][4 * i + 1] = fmaf(acc2[u][4 * i + 1], UNSCALE, b.y);
+                acc2[u][4 * i + 2] = fmaf(acc2[u][4 * i + 2], UNSCALE, b.z); acc2[u][4 * i + 3] = fmaf(acc2[u][4 * i + 3], UNSCALE, b.w);
+                s2 += (acc2[u][4 * i] + acc2[u][4 * i + 1]) + (acc2[u][4 * i + 2] + acc2[u][4 * i + 3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
     const float mean2 = (s2 + __shfl_xor(s2, 32)) * (1.f / H2);
     float ss2 = 0.f;
 #pragma unroll
@@ -399,24 +425,35 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     const float rstd2 = rsqrtf((ss2 + __shfl_xor(ss2, 32)) * (1.f / H2) + 1e-5f);
     const float av = (CRITIC && row < n) ? action[row] : 0.f;
     float dot = 0.f;
+    {
+        constexpr int NV = CRITIC ? 5 : 3;                  // gamma2, beta2, w3 (, wa, ba)
+        float4 vq[2][4][NV];
+        auto ldv = [&](const int u, float4 (&v)[4][NV]) {
 #pragma unroll
-    for (int u = 0; u < T2; ++u)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m0 = 32 * u + 8 * i + 4 * h;
-            const float4 g = *reinterpret_cast<const float4 *>(p2_s + H2P + m0);
-            const float4 be = *reinterpret_cast<const float4 *>(p2_s + 2 * H2P + m0);
-            const float4 w3 = *reinterpret_cast<const float4 *>(p2_s + 3 * H2P + m0);
-            float y0 = fmaf((acc2[u][4 * i] - mean2) * rstd2, g.x, be.x), y1 = fmaf((acc2[u][4 * i + 1] - mean2) * rstd2, g.y, be.y);
-            float y2 = fmaf((acc2[u][4 * i + 2] - mean2) * rstd2, g.z, be.z), y3 = fmaf((acc2[u][4 * i + 3] - mean2) * rstd2, g.w, be.w);
-            if (CRITIC) {
-                const float4 wa = *reinterpret_cast<const float4 *>(p2_s + 4 * H2P + m0);
-                const float4 ba = *reinterpret_cast<const float4 *>(p2_s + 5 * H2P + m0);
-                y0 += fmaf(av, wa.x, ba.x); y1 += fmaf(av, wa.y, ba.y); y2 += fmaf(av, wa.z, ba.z); y3 += fmaf(av, wa.w, ba.w);
+                for (int q = 0; q < NV; ++q) v[i][q] = *reinterpret_cast<const float4 *>(p2_s + (q + 1) * H2P + 32 * u + 8 * i + 4 * h);
+        };
+        ldv(0, vq[0]);
+#pragma unroll
+        for (int u = 0; u < T2; ++u) {
+            if (u + 1 < T2) ldv(u + 1, vq[(u + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 g = vq[u & 1][i][0], be = vq[u & 1][i][1], w3 = vq[u & 1][i][2];
+                float y0 = fmaf((acc2[u][4 * i] - mean2) * rstd2, g.x, be.x), y1 = fmaf((acc2[u][4 * i + 1] - mean2) * rstd2, g.y, be.y);
+                float y2 = fmaf((acc2[u][4 * i + 2] - mean2) * rstd2, g.z, be.z), y3 = fmaf((acc2[u][4 * i + 3] - mean2) * rstd2, g.w, be.w);
+                if (CRITIC) {
+                    const float4 wa = vq[u & 1][i][NV - 2], ba = vq[u & 1][i][NV - 1];
+                    y0 += fmaf(av, wa.x, ba.x); y1 += fmaf(av, wa.y, ba.y); y2 += fmaf(av, wa.z, ba.z); y3 += fmaf(av, wa.w, ba.w);
+                }
+                dot = fmaf(fmaxf(y0, 0.f), w3.x, dot); dot = fmaf(fmaxf(y1, 0.f), w3.y, dot);      // w3 = 0 on padding
+                dot = fmaf(fmaxf(y2, 0.f), w3.z, dot); dot = fmaf(fmaxf(y3, 0.f), w3.w, dot);
             }
-            dot = fmaf(fmaxf(y0, 0.f), w3.x, dot); dot = fmaf(fmaxf(y1, 0.f), w3.y, dot);      // w3 = 0 on padding
-            dot = fmaf(fmaxf(y2, 0.f), w3.z, dot); dot = fmaf(fmaxf(y3, 0.f), w3.w, dot);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
     const float v = dot + __shfl_xor(dot, 32) + p1_s[VEC_FLOATS];
     if (h == 0 && row < n) finish_row<CRITIC>(row, v, out, act);
     NSTAMP(5);
