@@ -240,6 +240,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_seconds)   # before any GPU call: its worker processes start from a GPU-free parent
 
+    if world > 1 and args.workload == "ddpg" and os.environ.get("TT_DIST_BACKEND", "nccl") == "nccl" \
+            and "TT_DP_GRAPH_COLLECTIVES" not in os.environ:
+        # one hipGraph per data-parallel step if this node replays a captured RCCL all-reduce correctly: asked in
+        # throw-away child processes before this rank touches its GPU (ddpg-trucktrailer_amd/dp_probe.py)
+        from ddpg_trucktrailer_amd.dp_probe import graph_collectives_ok
+        os.environ["TT_DP_GRAPH_COLLECTIVES"] = "1" if graph_collectives_ok() else "0"
+
     import torch
     import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path is a HIP kernel)"
@@ -313,7 +320,8 @@ def main():
                     f"batch {args.batch}, OU noise, replay ring {args.replay_slots}xN) (BASELINE config {5 if variant else 3})")
         if loop.graph_steps:
             launch = (f"every vector step a hipGraph replay: one graph of {loop.graph_steps} whole steps and one single-step graph "
-                      f"serve every ring position (device cursor)" if not loop.dp else
+                      f"serve every ring position (device cursor)" + (" -- the two RCCL gradient all-reduces of a step are nodes of its graph"
+                                                               if loop.dp else "") if not (loop.dp and not loop.dp_single_graph) else
                       "three hipGraph segments per step with the two RCCL gradient all-reduces between them")
         else:
             launch = "eager, learn() as a hipGraph" if loop.use_graph else "eager"

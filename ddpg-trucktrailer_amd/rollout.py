@@ -46,11 +46,15 @@ _SEED_STRIDE = 0x9E3779B97F4A7C15     # sampling key of update u of a vector ste
 class DDPGRollout:
     def __init__(self, env, batch_size=256, replay_slots=64, seed=27, alpha=1e-4, beta=1e-3, tau=1e-3, gamma=0.99,
                  fc1_dims=400, fc2_dims=300, world_size=1, use_graph=True, agent=None, fused_learn=True, graph_steps=4,
-                 updates_per_step=1, data_parallel=None, pipeline=None, policy_workgroups=192):
+                 updates_per_step=1, data_parallel=None, pipeline=None, policy_workgroups=192, graph_collectives=None):
         """updates_per_step: learn() calls per vector step (the reference does one per ENV step, trainv2.py:520-528; one
         per vector step is 1/N of that -- the knob moves the data/update ratio back towards the reference's).
         data_parallel: None = (world_size > 1); True forces the data-parallel launch structure with the process group's
-        real collectives even at world size 1 (tests of the RCCL path on one GPU)."""
+        real collectives even at world size 1 (tests of the RCCL path on one GPU).
+        graph_collectives (data-parallel, backend nccl only): the two gradient all-reduces are captured INSIDE the step's
+        hipGraph (RCCL launches are capturable), so a data-parallel step is one graph replay like a single-rank one instead
+        of three segments with eager collectives between them.  None = the TT_DP_GRAPH_COLLECTIVES environment variable
+        ("1" after dp_probe.graph_collectives_ok() saw a captured all-reduce replay correctly on this node)."""
         self.env, self.n, self.device = env, env.n_envs, env.device
         self.batch_size = batch_size
         self.updates_per_step = int(updates_per_step)
@@ -65,6 +69,12 @@ class DDPGRollout:
             capturable=use_graph, replay=False)
         if self.dp:
             self.agent.enable_data_parallel()
+        if graph_collectives is None:
+            graph_collectives = os.environ.get("TT_DP_GRAPH_COLLECTIVES") == "1"
+        self.dp_single_graph = False
+        if self.dp and graph_collectives:
+            import torch.distributed as dist
+            self.dp_single_graph = dist.is_initialized() and dist.get_backend() == "nccl"
         self.ring = TrajectoryRing(self.n, replay_slots, env.observation_dim, self.device)
         if self.device.type == "cuda":
             self.ring.attach(env)                          # the step kernel advances the ring's device counter
@@ -89,6 +99,7 @@ class DDPGRollout:
             # measurement aid: the data-parallel launch structure (three graph segments, separate Adam launches) on ONE
             # rank with no-op collectives -- what a rank's step costs before any time on the wire
             self.dp = True
+            self.dp_single_graph = os.environ.get("TT_DP_GRAPH_COLLECTIVES") == "1"
             self.learner.grad_sync_critic = self.learner.grad_sync_actor = lambda: None
         self.graph = None
         self._learn_side, self._learn_warm = None, 0
@@ -109,7 +120,7 @@ class DDPGRollout:
         self._view = self.ring.view() if self.ring_mode else None
         ok = self.use_graph and self.learner is not None and graph_steps and self.ring_mode
         self.graph_steps = int(graph_steps) if ok else 0
-        if self.graph_steps and self.dp:
+        if self.graph_steps and self.dp and not self.dp_single_graph:
             self.graph_steps = 1        # data-parallel: a step is three graphs with the two gradient all-reduces between
         self.graph1 = None              # one vector step (data-parallel: up to the critic's gradient)
         self.graphG = None              # graph_steps vector steps (one rank)
@@ -170,7 +181,7 @@ class DDPGRollout:
         # the autograd engine's thread and synchronises with whatever stream each parameter's gradient accumulator was
         # first used on -- a graph node kept alive elsewhere (a clone that carries its grad_fn, made on another stream) pulls
         # that stream into the capture, and HIP's EndCapture then takes the PROCESS down (no exception to fall back from).
-        if not self.use_graph or self.dp or self.learner is None:      # (collectives are not captured either)
+        if not self.use_graph or (self.dp and not self.dp_single_graph) or self.learner is None:   # (eager collectives)
             return self._learn_all()
         self._check_epoch()
         if self.graph is None:
@@ -281,12 +292,13 @@ class DDPGRollout:
 
     def _capture_body(self):
         """One whole vector step (data-parallel: up to the critic's gradient; the rest in _dp_step)."""
+        segments = self.dp and not self.dp_single_graph
         if self.pipeline:
-            self._pipelined(None, True, dp_capture=self.dp)
+            self._pipelined(None, True, dp_capture=segments)
             return
         self._open_step(False)
         self._act_and_step()
-        if self.dp:
+        if segments:
             s, a, r, s2, d = self._sample(0)
             self.learner.phase_a(s, a, r, s2, d, fuse_adam=False)
         else:
@@ -305,7 +317,7 @@ class DDPGRollout:
         assert getattr(ring, "_bufs", None) is not None, "sample buffers must exist before a capture (run a step first)"
         self.graph1 = self._capture(self._capture_body, side)
         self.graphG = self._capture(lambda: [self._capture_body() for _ in range(G)], side) if G > 1 else None
-        if self.dp:
+        if self.dp and not self.dp_single_graph:
             s = ring._bufs[0]
             self.dp_graphs = {}
             pieces = {"b": lambda: self.learner.phase_b(s, separate_adam=True), "c": self.learner.phase_c}
@@ -366,7 +378,7 @@ class DDPGRollout:
         while k > 0:
             G = self.graph_steps
             if G and ring.k >= 4 and (self._graphs_current() or self._try_capture()):
-                if self.dp:
+                if self.dp and not self.dp_single_graph:
                     self._dp_step()
                     done = 1
                 elif G > 1 and k >= G:

@@ -172,7 +172,11 @@ def _nccl_loop_worker(rank, world, port, out_dir):
     from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
     flats = []
     # graphs + RCCL / everything eager + RCCL / (one rank only) the single-rank launch structure without collectives
+    # the all-reduces as nodes of ONE graph per step (only where this node replays a captured collective correctly: every
+    # rank asks the probe's answer from the environment, set by the test before the ranks start)
     variants = [dict(graph_steps=4, data_parallel=True), dict(graph_steps=0, data_parallel=True)]
+    if os.environ.get("TT_TEST_GRAPH_COLLECTIVES") == "1":
+        variants.append(dict(graph_steps=4, data_parallel=True, graph_collectives=True))
     if world == 1:
         variants.append(dict(graph_steps=4, data_parallel=False))
     for kw in variants:
@@ -183,7 +187,10 @@ def _nccl_loop_worker(rank, world, port, out_dir):
         loop.run(13)
         torch.cuda.synchronize()
         if kw["graph_steps"]:
-            assert loop.graph1 is not None and (loop.dp_graphs is not None) == loop.dp
+            single = bool(kw.get("graph_collectives"))
+            assert loop.dp_single_graph == single
+            assert loop.graph1 is not None and (loop.dp_graphs is not None) == (loop.dp and not single)
+            assert (loop.graphG is not None) == (single or not loop.dp)
         flats.append(torch.cat([p.detach().reshape(-1) for net in loop.agent._nets() for p in net.parameters()]).cpu())
         env.close()
     torch.save(flats, os.path.join(out_dir, f"nccl{rank}.pt"))
@@ -197,11 +204,29 @@ def test_rccl_world_size_1_loop_graphs_match_eager(tmp_path, gpu_device):
     buffers, the three graph segments captured with a live communicator.  Graph path == eager path bit for bit, and
     (AVG over one rank being the identity) == the single-rank loop whose Adam runs inside the weight-gradient launch."""
     port = _free_port()
-    mp.start_processes(_nccl_loop_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True, start_method="spawn")
+    os.environ["TT_TEST_GRAPH_COLLECTIVES"] = "1"
+    try:
+        mp.start_processes(_nccl_loop_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True, start_method="spawn")
+    finally:
+        os.environ.pop("TT_TEST_GRAPH_COLLECTIVES", None)
     a = torch.load(tmp_path / "nccl0.pt", weights_only=True)
     assert torch.isfinite(a[0]).all()
     assert torch.equal(a[0], a[1]), "graph path differs from the eager path under RCCL"
-    assert torch.equal(a[0], a[2]), "data-parallel structure at world size 1 differs from the single-rank loop"
+    assert torch.equal(a[0], a[2]), "one graph per step with the all-reduces captured in it differs from the eager path"
+    assert torch.equal(a[0], a[3]), "data-parallel structure at world size 1 differs from the single-rank loop"
+
+
+@pytest.mark.gpu
+def test_graph_collective_probe_world_size_1(gpu_device):
+    """dp_probe: a child process captures an AVG all-reduce into a hipGraph, replays it and checks the numbers; the
+    caller (a process that has not touched a GPU: a fresh interpreter here) gets True.  One rank on the test box."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               TT_DP_PROBE_FORCE="1")
+    code = ("import sys; sys.path.insert(0, %r); from ddpg_trucktrailer_amd.dp_probe import graph_collectives_ok; "
+            "print('answer', graph_collectives_ok(200.0))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "answer True" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
@@ -211,11 +236,34 @@ def test_rccl_n_rank_loop(tmp_path, gpu_device, world):
     if torch.cuda.device_count() < world:
         pytest.skip(f"needs {world} GPUs")
     port = _free_port()
-    mp.start_processes(_nccl_loop_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    from ddpg_trucktrailer_amd.dp_probe import graph_collectives_ok
+    probe_env = dict(WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1")
+    # (the probe's children are one per rank: ask for all of them from here, rank by rank, in threads)
+    import threading
+    answers = [False] * world
+    def ask(r):
+        import subprocess
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), MASTER_PORT=str(port + 7), **probe_env)
+        code = ("import sys; sys.path.insert(0, %r); from ddpg_trucktrailer_amd.dp_probe import graph_collectives_ok; "
+                "print('answer', graph_collectives_ok(200.0))" % ROOT)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=400)
+        answers[r] = "answer True" in out.stdout
+    threads = [threading.Thread(target=ask, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    single = all(answers)
+    if single:
+        os.environ["TT_TEST_GRAPH_COLLECTIVES"] = "1"
+    try:
+        mp.start_processes(_nccl_loop_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    finally:
+        os.environ.pop("TT_TEST_GRAPH_COLLECTIVES", None)
     flats = [torch.load(tmp_path / f"nccl{r}.pt", weights_only=True) for r in range(world)]
     for r in range(1, world):
-        assert torch.equal(flats[0][0], flats[r][0]) and torch.equal(flats[0][1], flats[r][1]), "ranks diverged"
+        assert all(torch.equal(a, b) for a, b in zip(flats[0], flats[r])), "ranks diverged"
     assert torch.equal(flats[0][0], flats[0][1]), "graph path differs from the eager path"
+    if single:
+        assert torch.equal(flats[0][0], flats[0][2]), "in-graph all-reduces differ from the eager path"
     assert torch.isfinite(flats[0][0]).all()
 
 
