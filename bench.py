@@ -36,8 +36,8 @@ PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)      # >= 200 warm vector steps, then >= 2000 timed
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--n-envs", type=int, default=65536, help="envs PER GPU (weak scaling)")
     ap.add_argument("--workload", choices=("ddpg", "env"), default="ddpg")
     ap.add_argument("--variant", choices=("simv2", "simv1"), default="simv2")

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from ddpg_trucktrailer_amd import _lib as L
+from ddpg_trucktrailer_amd import fused
 from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
 
 
@@ -53,8 +54,13 @@ def generate_heatmap_data(actor, grid_resolution=2.0, trials_per_cell=5, map_x_r
     first = torch.arange(0, n, nt, device=dev)             # lane of trial 0 of every cell (its trajectory is kept)
     traj = [env.state[first][:, 4:6].cpu().numpy()]
     traj_len = torch.ones(len(first), dtype=torch.int64, device=dev)
+    # the reference-shaped actor on the GPU goes through the fused forward (csrc/ttnet_split.hip: all 7,000 lanes in one
+    # launch at f32 accuracy); any other module, or the CPU, through torch
+    use_fused = dev.type == "cuda" and fused.supported(actor)
+    mu = torch.empty(n, dtype=torch.float32, device=dev)
     for _ in range(max_steps_cap):
-        action = torch.clamp(actor(obs).view(-1), -1.0, 1.0) * high        # evaluate=True: no noise (heatmap.py:138)
+        mu_now = fused.actor_forward(actor, obs, mu).view(-1) if use_fused else actor(obs).view(-1)
+        action = torch.clamp(mu_now, -1.0, 1.0) * high                     # evaluate=True: no noise (heatmap.py:138)
         obs, _, done, info = env.step(action, auto_reset=False, info=True)
         live = ~finished
         score += torch.where(live, info["comp"][0], torch.zeros_like(score))
