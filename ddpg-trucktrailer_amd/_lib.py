@@ -34,7 +34,7 @@ class TTInfo(C.Structure):
 
 class TTMlpWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "w3", "b3", "wa", "ba")] + \
-               [("in_dim", C.c_int32), ("fc1_dims", C.c_int32), ("fc2_dims", C.c_int32), ("reserved_", C.c_int32),
+               [("in_dim", C.c_int32), ("fc1_dims", C.c_int32), ("fc2_dims", C.c_int32), ("capped_grids", C.c_int32),
                 ("split_ws", C.c_void_p), ("ws_packed", C.c_int32), ("max_workgroups", C.c_int32)]
 
 

@@ -501,13 +501,21 @@ static int launch_split(int n, const float *obs, const float *action, const tt_m
     // many workgroups, so that never more than that many CUs are busy with this forward (the rest stay free for launches on
     // other streams); 0: one grid, the hardware takes the tiles in rounds
     const int ntiles = (n + ROWS - 1) / ROWS;
+    // capped_grids > 0: only that many grids are capped -- what the cap makes room for is over by then -- and the rest of the
+    // tiles go out in one grid over the whole chip
     const int limit = w->max_workgroups > 0 ? w->max_workgroups : ntiles;
-    const int grids = (ntiles + limit - 1) / limit, cap = (ntiles + grids - 1) / grids;      // equal shares: 512 tiles, limit 192 -> 171, 171, 170
-    for (int t0 = 0; t0 < ntiles; t0 += cap) {
-        const int g = ntiles - t0 < cap ? ntiles - t0 : cap;
+    int capped = ntiles;
+    if (w->max_workgroups > 0 && w->capped_grids > 0 && (long long)w->capped_grids * limit < ntiles)
+        capped = w->capped_grids * limit;
+    const int grids = (capped + limit - 1) / limit, cap = (capped + grids - 1) / grids;      // equal shares: 512 tiles, limit 192 -> 171, 171, 170
+    for (int t0 = 0; t0 < capped; t0 += cap) {
+        const int g = capped - t0 < cap ? capped - t0 : cap;
         hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(g), dim3(256), LDS_BYTES, stream, n, t0, obs, action,
                            reinterpret_cast<const unsigned char *>(w->split_ws), out, act);
     }
+    if (capped < ntiles)
+        hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(ntiles - capped), dim3(256), LDS_BYTES, stream, n, capped, obs, action,
+                           reinterpret_cast<const unsigned char *>(w->split_ws), out, act);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 

@@ -72,7 +72,7 @@ def weights_of(net):
     return w
 
 
-def packed_weights_of(net, index, max_workgroups=None):
+def packed_weights_of(net, index, max_workgroups=None, capped_grids=None):
     """TTMlpWeights whose split-kernel image is kept current BY THE CALLER (pack()): one of two private workspaces per
     module (index 0 / 1), so a loop can fill the image for the next step while a forward still reads this step's.
     Forwards through it never re-pack and read nothing of the live parameters."""
@@ -86,6 +86,8 @@ def packed_weights_of(net, index, max_workgroups=None):
         hit = cache[index] = (key, w, ws)
     if max_workgroups is not None:
         hit[1].max_workgroups = int(max_workgroups)
+    if capped_grids is not None:
+        hit[1].capped_grids = int(capped_grids)
     return hit[1]
 
 

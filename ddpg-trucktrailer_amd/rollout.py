@@ -46,7 +46,8 @@ _SEED_STRIDE = 0x9E3779B97F4A7C15     # sampling key of update u of a vector ste
 class DDPGRollout:
     def __init__(self, env, batch_size=256, replay_slots=64, seed=27, alpha=1e-4, beta=1e-3, tau=1e-3, gamma=0.99,
                  fc1_dims=400, fc2_dims=300, world_size=1, use_graph=True, agent=None, fused_learn=True, graph_steps=4,
-                 updates_per_step=1, data_parallel=None, pipeline=None, policy_workgroups=192, graph_collectives=None):
+                 updates_per_step=1, data_parallel=None, pipeline=None, policy_workgroups=192, graph_collectives=None,
+                 policy_capped_grids=4):
         """updates_per_step: learn() calls per vector step (the reference does one per ENV step, trainv2.py:520-528; one
         per vector step is 1/N of that -- the knob moves the data/update ratio back towards the reference's).
         data_parallel: None = (world_size > 1); True forces the data-parallel launch structure with the process group's
@@ -108,6 +109,9 @@ class DDPGRollout:
             and self.ring._env_counts
         self.pipeline = can_pipe if pipeline is None else (bool(pipeline) and can_pipe)
         self.policy_workgroups = int(os.environ.get("TT_POLICY_WG", policy_workgroups))     # (env: A/B measurements)
+        # learn() is over after about four of the policy's capped grids (~100 us): the tiles left then (N > 98304 envs) go out
+        # in one grid over all CUs
+        self.policy_capped_grids = int(os.environ.get("TT_POLICY_CAPPED_GRIDS", policy_capped_grids))
         self.k_pipe_dev = torch.zeros((), dtype=torch.int64, device=self.device)   # steps completed before the running one
         self._pipe_side = None
         if self.pipeline:
@@ -133,7 +137,7 @@ class DDPGRollout:
         if self.fused_act:     # actor forward + OU noise + clip*high in ONE launch (tt_actor_act)
             w = None
             if self.pipeline:  # the image packed at the start of this step, never the live weights learn() is updating
-                w = fused.packed_weights_of(self.agent.actor, 0, self.policy_workgroups)
+                w = fused.packed_weights_of(self.agent.actor, 0, self.policy_workgroups, self.policy_capped_grids)
             if self.ring._env_counts:      # noise keyed by the DEVICE step counter: the launch is graph-replayable
                 return fused.actor_act(self.agent.actor, obs, self.noise.x, act_out, self.scaled, seed=self.seed,
                                        step=0, step_dev=self.ring.k_dev, done_prev=done_prev, high=self.high, weights=w)
@@ -217,7 +221,8 @@ class DDPGRollout:
 
     def policy_launch(self):
         """The policy launch of the running step alone (ring mode; after _open_step): bench.py times it."""
-        w = fused.packed_weights_of(self.agent.actor, 0, self.policy_workgroups if self.pipeline else 0)
+        w = fused.packed_weights_of(self.agent.actor, 0, self.policy_workgroups if self.pipeline else 0,
+                                    self.policy_capped_grids)
         return fused.actor_act_ring(self.agent.actor, self._view, w, self.noise.x, self.scaled, seed=self.seed, step=0,
                                     step_dev=self.ring.k_dev, high=self.high)
 

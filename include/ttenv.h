@@ -220,7 +220,10 @@ int tt_random_actions(int n, uint64_t seed, uint64_t step, float *out, tt_stream
  * split_ws = NULL always selects the exact-f32 kernel.  Structs of gradients (tt_mlp_backward) ignore it. */
 typedef struct tt_mlp_weights {
     const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *w3, *b3, *wa, *ba;
-    int32_t in_dim, fc1_dims, fc2_dims, reserved_;
+    int32_t in_dim, fc1_dims, fc2_dims;
+    int32_t capped_grids;   /* with max_workgroups > 0: > 0 = only the first capped_grids grids are capped, the remaining tiles go
+                               out in ONE grid over the whole chip (large n: the launches on other streams that the cap makes room
+                               for are over after a few grids); 0 = every grid is capped */
     void *split_ws;
     int32_t ws_packed;      /* != 0: split_ws already holds the image of these weights (tt_mlp_split_pack): forwards do not
                                re-pack and read nothing but the image, so the weights may be updated beside them */

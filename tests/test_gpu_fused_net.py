@@ -133,3 +133,28 @@ def test_fused_choose_action_epilogue(gpu_device):
     again = before.clone()
     fused.actor_act(actor, obs, again, raw, scaled, seed=27, step=100, done_prev=done, high=high)
     assert torch.equal(again, ou)                                                    # step + *step_dev is the counter
+
+
+def test_launch_geometry_does_not_change_results(gpu_device):
+    """The split kernel's tiles in one grid, in capped grids (tt_mlp_weights.max_workgroups) and in a few capped grids
+    followed by one whole-chip grid (capped_grids) are the same rows computed by the same code: bit-identical."""
+    import torch
+    from ddpg_trucktrailer_amd import fused
+    actor, _ = _nets(gpu_device, seed=9)
+    n = 128 * 37 + 55                                   # 38 tiles, the last one ragged
+    obs = torch.rand((n, 23), device=gpu_device) * 2 - 1
+    fused.pack(actor, 1)
+    outs = []
+    for wg, capped in ((0, 0), (8, 0), (8, 2), (5, 1), (64, 3)):
+        w = fused.packed_weights_of(actor, 1, wg, capped)
+        out = torch.full((n,), float("nan"), device=gpu_device)
+        from ddpg_trucktrailer_amd import _lib as L
+        import ctypes as C
+        L.check(L.load().tt_actor_forward(n, C.c_void_p(obs.data_ptr()), C.byref(w), C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)))
+        outs.append(out.clone())
+    fused.packed_weights_of(actor, 1, 0, 0)
+    with torch.no_grad():
+        assert (outs[0].view(-1, 1) - actor(obs)).abs().max().item() <= 2e-5
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
