@@ -91,6 +91,13 @@ __device__ __forceinline__ void split2(const float x0, const float x1, uint32_t 
     pm = __builtin_bit_cast(uint32_t, m);
 }
 
+// Packed f32 arithmetic (v_pk_add/mul/fma_f32: two lanes' worth of f32 per instruction at the same issue cost): the
+// vector phases of the forward are issue-bound on one wave per SIMD, and their operands (accumulator registers, float4s of
+// per-neuron vectors) already sit in even-aligned register pairs.  Component-wise IEEE fma: the same numbers as scalar code.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 pk(const float a, const float b) { return f32x2{a, b}; }
+__device__ __forceinline__ f32x2 pk_fma(const f32x2 a, const f32x2 b, const f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 __device__ __forceinline__ f32x16 mfma_f16(const uint4 a, const uint4 b, const f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -189,6 +196,17 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    // this lane's view of the per-neuron vectors, its address held in a register: the region lies beyond the 64 KB a
+    // ds_read's immediate offset reaches from address 0, and left to itself the compiler forms every address with an add
+    using lds_f = const __attribute__((address_space(3))) float;
+    using v4 = __attribute__((ext_vector_type(4))) float;
+    auto lds4 = [](lds_f *q) -> float4 {
+        const v4 t = *(const __attribute__((address_space(3))) v4 *)q;
+        return make_float4(t[0], t[1], t[2], t[3]);
+    };
+    lds_f *pv1 = (lds_f *)(p1_s + 4 * h);
+    asm volatile("" : "+v"(pv1));
+    lds_f *pv2 = pv1 + 2 * H1P;
     // One 128-env tile per workgroup (a loop over tiles inside the kernel costs ~400 spilled registers: the compiler hoists
     // the tile-invariant DMA addresses); a caller that wants CUs left free launches the tiles in several grids (tile0).
     const int tile = tile0 + blockIdx.x;
@@ -278,20 +296,28 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     // 1/sigma absorbs the scale; then gamma*SX, beta*SX and ReLU give the layer-2 operand already scaled by SX.
     // Tile 12 holds neurons 384..399 in v < 8.
     {
-        float s = 0.f;
+        f32x2 sp = pk(0.f, 0.f);
 #pragma unroll
         for (int t = 0; t < T1; ++t)
 #pragma unroll
             for (int v = 0; v < (t == T1 - 1 ? 8 : 16); v += 4)
-                s += (acc1[t][v] + acc1[t][v + 1]) + (acc1[t][v + 2] + acc1[t][v + 3]);
+                sp += pk(acc1[t][v], acc1[t][v + 1]) + pk(acc1[t][v + 2], acc1[t][v + 3]);
+        const float s = sp[0] + sp[1];
         const float mean = (s + __shfl_xor(s, 32)) * (1.f / H1);
-        float ss = 0.f;
+        const f32x2 nmean = pk(-mean, -mean);
+        f32x2 ssp = pk(0.f, 0.f);
 #pragma unroll
         for (int t = 0; t < T1; ++t)
 #pragma unroll
-            for (int v = 0; v < (t == T1 - 1 ? 8 : 16); ++v) { acc1[t][v] -= mean; ss = fmaf(acc1[t][v], acc1[t][v], ss); }
+            for (int v = 0; v < (t == T1 - 1 ? 8 : 16); v += 2) {
+                const f32x2 d = pk(acc1[t][v], acc1[t][v + 1]) + nmean;
+                acc1[t][v] = d[0]; acc1[t][v + 1] = d[1];
+                ssp = pk_fma(d, d, ssp);
+            }
+        const float ss = ssp[0] + ssp[1];
         const float var = (ss + __shfl_xor(ss, 32)) * (1.f / H1) * (UNSCALE * UNSCALE);
         const float rstd = rsqrtf(var + 1e-5f) * UNSCALE;
+        const f32x2 rstdp = pk(rstd, rstd);
         // gamma*SX, beta*SX, ReLU, then straight into the two f16 pieces layer 2 multiplies with: hb[s] / mb[s] are the
         // B fragments (h, m planes) of k16 step s -- element j of lane half h is neuron 16 s + 8 (j >> 2) + 4 h + (j & 3),
         // i.e. registers 8 (s & 1) .. + 7 of tile s >> 1, the order the packed fc2 fragments are laid out in
@@ -301,8 +327,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
         auto ld1 = [&](const int t, float4 (&g)[4], float4 (&be)[4]) {
 #pragma unroll
             for (int i = 0; i < (t == T1 - 1 ? 2 : 4); ++i) {
-                g[i] = *reinterpret_cast<const float4 *>(p1_s + 32 * t + 8 * i + 4 * h);
-                be[i] = *reinterpret_cast<const float4 *>(p1_s + H1P + 32 * t + 8 * i + 4 * h);
+                g[i] = lds4(pv1 + 32 * t + 8 * i);
+                be[i] = lds4(pv1 + H1P + 32 * t + 8 * i);
             }
         };
         ld1(0, gq[0], bq[0]);
@@ -313,10 +339,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
 #pragma unroll
             for (int i = 0; i < (t == T1 - 1 ? 2 : 4); ++i) {
                 const float4 g = gq[t & 1][i], be = bq[t & 1][i];
-                const float y0 = fmaxf(fmaf(acc1[t][4 * i] * rstd, g.x, be.x), 0.f);
-                const float y1 = fmaxf(fmaf(acc1[t][4 * i + 1] * rstd, g.y, be.y), 0.f);
-                const float y2 = fmaxf(fmaf(acc1[t][4 * i + 2] * rstd, g.z, be.z), 0.f);
-                const float y3 = fmaxf(fmaf(acc1[t][4 * i + 3] * rstd, g.w, be.w), 0.f);
+                const f32x2 ya = pk_fma(pk(acc1[t][4 * i], acc1[t][4 * i + 1]) * rstdp, pk(g.x, g.y), pk(be.x, be.y));
+                const f32x2 yb = pk_fma(pk(acc1[t][4 * i + 2], acc1[t][4 * i + 3]) * rstdp, pk(g.z, g.w), pk(be.z, be.w));
+                const float y0 = fmaxf(ya[0], 0.f), y1 = fmaxf(ya[1], 0.f), y2 = fmaxf(yb[0], 0.f), y3 = fmaxf(yb[1], 0.f);
                 const int st = 2 * t + (i >> 1), e = 2 * (i & 1);             // k16 step, first of its two packed registers
                 split2(y0, y1, hb[st][e], mb[st][e]);
                 split2(y2, y3, hb[st][e + 1], mb[st][e + 1]);
@@ -390,12 +415,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     // ---- epilogue: scale back + bias, LayerNorm(300), (critic: + action_value(a)), ReLU, head; acc2[u][v] is neuron
     // 32u + 8(v>>2) + 4h + (v&3); 300 = 9*32 + 12, so groups of four are all real or all padding
     // (the per-neuron vectors are read from LDS one tile ahead of their use, as in LayerNorm 1)
-    float s2 = 0.f;
+    f32x2 s2p = pk(0.f, 0.f);
     {
         float4 bq[2][4];
         auto ldb = [&](const int u, float4 (&b)[4]) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const float4 *>(p2_s + 32 * u + 8 * i + 4 * h);   // zero beyond 300
+            for (int i = 0; i < 4; ++i) b[i] = lds4(pv2 + 32 * u + 8 * i);   // zero beyond 300
         };
         ldb(0, bq[0]);
 #pragma unroll
@@ -405,26 +430,38 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float4 b = bq[u & 1][i];
-                acc2[u][4 * i] = fmaf(acc2[u][4 * i], UNSCALE, b.x); acc2[u][4 * i + 1] = fmaf(acc2[u][4 * i + 1], UNSCALE, b.y);
-                acc2[u][4 * i + 2] = fmaf(acc2[u][4 * i + 2], UNSCALE, b.z); acc2[u][4 * i + 3] = fmaf(acc2[u][4 * i + 3], UNSCALE, b.w);
-                s2 += (acc2[u][4 * i] + acc2[u][4 * i + 1]) + (acc2[u][4 * i + 2] + acc2[u][4 * i + 3]);
+                const f32x2 xa = pk_fma(pk(acc2[u][4 * i], acc2[u][4 * i + 1]), pk(UNSCALE, UNSCALE), pk(b.x, b.y));
+                const f32x2 xb2 = pk_fma(pk(acc2[u][4 * i + 2], acc2[u][4 * i + 3]), pk(UNSCALE, UNSCALE), pk(b.z, b.w));
+                acc2[u][4 * i] = xa[0]; acc2[u][4 * i + 1] = xa[1]; acc2[u][4 * i + 2] = xb2[0]; acc2[u][4 * i + 3] = xb2[1];
+                s2p += xa + xb2;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    const float s2 = s2p[0] + s2p[1];
     const float mean2 = (s2 + __shfl_xor(s2, 32)) * (1.f / H2);
-    float ss2 = 0.f;
+    const f32x2 nmean2 = pk(-mean2, -mean2);
+    // deviations in place (the last pass needs nothing else of the pre-activations); padding groups do not count
+    f32x2 ss2p = pk(0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < T2; ++u)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool real = 32 * u + 8 * i + 4 * h < H2;
+            const f32x2 keep = real ? pk(1.f, 1.f) : pk(0.f, 0.f);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const float d = real ? acc2[u][4 * i + j] - mean2 : 0.f; ss2 = fmaf(d, d, ss2); }
+            for (int j = 0; j < 4; j += 2) {
+                const f32x2 d = pk(acc2[u][4 * i + j], acc2[u][4 * i + j + 1]) + nmean2;
+                acc2[u][4 * i + j] = d[0]; acc2[u][4 * i + j + 1] = d[1];
+                const f32x2 dk = (32 * u + 8 * i + 4 < H2) ? d : d * keep;      // only the last tiles can hold padding
+                ss2p = pk_fma(dk, dk, ss2p);
+            }
         }
+    const float ss2 = ss2p[0] + ss2p[1];
     const float rstd2 = rsqrtf((ss2 + __shfl_xor(ss2, 32)) * (1.f / H2) + 1e-5f);
+    const f32x2 rstd2p = pk(rstd2, rstd2);
     const float av = (CRITIC && row < n) ? action[row] : 0.f;
-    float dot = 0.f;
+    f32x2 dotp = pk(0.f, 0.f);
     {
         constexpr int NV = CRITIC ? 5 : 3;                  // gamma2, beta2, w3 (, wa, ba)
         float4 vq[2][4][NV];
@@ -432,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int q = 0; q < NV; ++q) v[i][q] = *reinterpret_cast<const float4 *>(p2_s + (q + 1) * H2P + 32 * u + 8 * i + 4 * h);
+                for (int q = 0; q < NV; ++q) v[i][q] = lds4(pv2 + (q + 1) * H2P + 32 * u + 8 * i);
         };
         ldv(0, vq[0]);
 #pragma unroll
@@ -442,18 +479,20 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float4 g = vq[u & 1][i][0], be = vq[u & 1][i][1], w3 = vq[u & 1][i][2];
-                float y0 = fmaf((acc2[u][4 * i] - mean2) * rstd2, g.x, be.x), y1 = fmaf((acc2[u][4 * i + 1] - mean2) * rstd2, g.y, be.y);
-                float y2 = fmaf((acc2[u][4 * i + 2] - mean2) * rstd2, g.z, be.z), y3 = fmaf((acc2[u][4 * i + 3] - mean2) * rstd2, g.w, be.w);
+                f32x2 ya = pk_fma(pk(acc2[u][4 * i], acc2[u][4 * i + 1]) * rstd2p, pk(g.x, g.y), pk(be.x, be.y));
+                f32x2 yb = pk_fma(pk(acc2[u][4 * i + 2], acc2[u][4 * i + 3]) * rstd2p, pk(g.z, g.w), pk(be.z, be.w));
                 if (CRITIC) {
                     const float4 wa = vq[u & 1][i][NV - 2], ba = vq[u & 1][i][NV - 1];
-                    y0 += fmaf(av, wa.x, ba.x); y1 += fmaf(av, wa.y, ba.y); y2 += fmaf(av, wa.z, ba.z); y3 += fmaf(av, wa.w, ba.w);
+                    ya += pk_fma(pk(av, av), pk(wa.x, wa.y), pk(ba.x, ba.y));
+                    yb += pk_fma(pk(av, av), pk(wa.z, wa.w), pk(ba.z, ba.w));
                 }
-                dot = fmaf(fmaxf(y0, 0.f), w3.x, dot); dot = fmaf(fmaxf(y1, 0.f), w3.y, dot);      // w3 = 0 on padding
-                dot = fmaf(fmaxf(y2, 0.f), w3.z, dot); dot = fmaf(fmaxf(y3, 0.f), w3.w, dot);
+                dotp = pk_fma(pk(fmaxf(ya[0], 0.f), fmaxf(ya[1], 0.f)), pk(w3.x, w3.y), dotp);      // w3 = 0 on padding
+                dotp = pk_fma(pk(fmaxf(yb[0], 0.f), fmaxf(yb[1], 0.f)), pk(w3.z, w3.w), dotp);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    const float dot = dotp[0] + dotp[1];
     const float v = dot + __shfl_xor(dot, 32) + p1_s[VEC_FLOATS];
     if (h == 0 && row < n) finish_row<CRITIC>(row, v, out, act);
     NSTAMP(5);
