@@ -35,7 +35,11 @@ class TTInfo(C.Structure):
 class TTMlpWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "w3", "b3", "wa", "ba")] + \
                [("in_dim", C.c_int32), ("fc1_dims", C.c_int32), ("fc2_dims", C.c_int32), ("capped_grids", C.c_int32),
-                ("split_ws", C.c_void_p), ("ws_packed", C.c_int32), ("max_workgroups", C.c_int32)]
+                ("split_ws", C.c_void_p), ("ws_packed", C.c_int32), ("max_workgroups", C.c_int32), ("fc2_img", C.c_void_p)]
+
+
+class TTFc2Images(C.Structure):
+    _fields_ = [("net", C.c_void_p), ("target", C.c_void_p)]
 
 
 class TTMlpSaved(C.Structure):
@@ -140,9 +144,11 @@ _SIGNATURES = {
                                             C.POINTER(TTMlpBwdWs), _P]),
     "tt_mlp_backward_weights": (C.c_int, [_I, _I, _P, _P, C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights),
                                           _P, _P, C.c_float, _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
-                                          C.c_float, C.c_float, _P]),
+                                          C.c_float, C.c_float, C.POINTER(TTFc2Images), _P]),
     "tt_adam_soft_update": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
-                                      C.c_float, C.c_float, _P]),
+                                      C.c_float, C.c_float, C.POINTER(TTFc2Images), _P]),
+    "tt_mlp_fc2_image_bytes": (C.c_uint64, []),
+    "tt_mlp_fc2_image_pack": (C.c_int, [C.POINTER(TTMlpWeights), _P]),
     "tt_td_target": (C.c_int, [_I, _P, _P, _P, C.c_float, _P, _P, _P]),
     "tt_random_actions": (C.c_int, [_I, _U64, _U64, _P, _P]),
 }

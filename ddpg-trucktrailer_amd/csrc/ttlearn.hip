@@ -38,6 +38,47 @@ constexpr int DS = 308;                  // LDS row stride of the 16 x 300 tiles
                                           // with K = 304): 16-byte rows
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+// ---- fc2 products on the f16 MFMA from a pre-split image of the weights (tt_mlp_weights.fc2_img; include/ttenv.h) ----
+// An f32 number is, to within its own rounding, the sum of two round-to-nearest f16 numbers (csrc/ttnet_split.hip has the
+// argument): x*w = h*h' + h*m' + m*h' to ~2^-22, three v_mfma_f32_16x16x32_f16 per block at 16x the f32 MFMA rate.  The
+// weights' pieces come ready from the image (the optimizer launches keep it current element by element), the activations
+// / gradients of a workgroup's 16 rows are split once into LDS planes.  Scales: activations x16, weights x64, gradient rows
+// by a per-row power of two (so the m pieces stay normal); all exact.
+constexpr int K2P = 416;                 // fc2 inputs padded to whole k32 steps (13)
+constexpr int N2P = 320;                 // fc2 outputs padded to whole k32 steps (10) / tiles (20)
+constexpr int HSH = 424;                 // LDS row stride (halves) of the 16 x 416 planes: 212 dwords, 212 mod 64 = 20 (as HS1)
+constexpr int DSH = 328;                 // ... of the 16 x 320 planes: 164 dwords, 164 mod 64 = 36: a b128 fragment read is conflict-free
+// The image holds MFMA fragments, 1 KB each (64 lanes x 8 halves = what ONE global_load_dwordx4 of a wave fetches, fully
+// coalesced), in two orientations, an h and an m plane of each:
+//   forward  [20 tiles][13 k32 steps][64 lanes][8]: lane (l15, l4) of tile T holds W2[n = 16 T + l15][k = 32 s + 8 l4 + j];
+//   backward [28 tiles][10 k32 steps][64 lanes][8]: dH1 = dX2 * W2 sums over n; tile T = 4 g + t serves output column
+//            k = 64 g + 4 l15 + t (the accumulator mapping of the f32 path: a lane's four tiles are four consecutive columns),
+//            lane (l15, l4) holds W2[n = 32 s + 8 l4 + j][k]; tiles beyond column 399 stay zero.
+constexpr int FW_TILES = N2P / 16, FW_STEPS = K2P / 32, BW_TILES = 28, BW_STEPS = N2P / 32;
+constexpr size_t IMG_FWD = (size_t)FW_TILES * FW_STEPS * 512, IMG_T = (size_t)BW_TILES * BW_STEPS * 512;   // halves per plane
+constexpr size_t IMG_HALVES = 2 * IMG_FWD + 2 * IMG_T;                       // 1,105,920 bytes
+constexpr float SXL = 16.f, SWL = 64.f, UNSC_L = 1.f / (SXL * SWL);
+constexpr int H1S_FLOATS = 16 * HSH;     // floats of the activation tile's LDS buffer: 16 x 404 f32, or the two 16 x 424 f16 planes
+constexpr int DXS_FLOATS = 16 * DSH;     // ... of the dX2 tile's: 16 x 308 f32, or the two 16 x 328 f16 planes
+__device__ __forceinline__ f32x4 mfma_h(const f16x8 a, const f16x8 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// the two pieces of one fc2 weight into an image: element (n = output neuron, k = input)
+__device__ __forceinline__ void img_store(_Float16 *__restrict__ img, const int n, const int k, const float w, const bool with_t) {
+    const float s = w * SWL;
+    const _Float16 h = (_Float16)s, m = (_Float16)(s - (float)h);
+    const size_t f = ((size_t)((n >> 4) * FW_STEPS + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7);
+    img[f] = h;
+    img[IMG_FWD + f] = m;
+    if (with_t) {
+        const int tile = (k >> 6) * 4 + (k & 3), l15 = (k >> 2) & 15;
+        const size_t b = ((size_t)(tile * BW_STEPS + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + l15) * 8 + (n & 7);
+        img[2 * IMG_FWD + b] = h;
+        img[2 * IMG_FWD + IMG_T + b] = m;
+    }
+}
 
 #ifdef TT_STAMPS   // diagnostic build only: wall-clock stamps (100 MHz) of workgroup 0 / wave 0 at phase boundaries
 __device__ unsigned long long g_stamps[32];
@@ -55,6 +96,7 @@ struct Weights {
     const float *__restrict__ w1, *__restrict__ b1, *__restrict__ g1, *__restrict__ be1, *__restrict__ w2,
         *__restrict__ b2, *__restrict__ g2, *__restrict__ be2, *__restrict__ w3, *__restrict__ b3, *__restrict__ wa,
         *__restrict__ ba;
+    const _Float16 *__restrict__ img;     // fc2 image (nullptr: products on the f32 MFMA from w2)
 };
 struct Saved {          // forward activations kept for the backward (all [B, .] row-major f32)
     float *__restrict__ xh1, *__restrict__ h1;    // [B,400] normalised fc1 output (before gamma/beta), post-ReLU activation
@@ -82,6 +124,17 @@ __device__ __forceinline__ float wave_sum64(float v) {
     const int u = __builtin_bit_cast(int, row_sum16(v));
     return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16))) +
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48)));
+}
+
+// max over the wave of a non-negative number; the result is wave-uniform
+__device__ __forceinline__ float wave_max64(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    const int u = __builtin_bit_cast(int, v);
+    return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 16))),
+                 fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48))));
 }
 
 // combine a per-wave, per-row partial (valid in every lane of the 16-lane group of that row) across the 4 waves.
@@ -187,15 +240,29 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
         }
     }
     __syncthreads();
-    // bias, LayerNorm(400) (biased variance, eps 1e-5), ReLU for this wave's two rows
+    // bias, LayerNorm(400) (biased variance, eps 1e-5), ReLU for this wave's two rows.  With an fc2 image the rows leave as
+    // the two f16 planes of the layer-2 operand, which share the buffer with the f32 tile: every wave has read its rows
+    // before any plane is written
+    const bool img = W.img != nullptr;                     // (uniform over the launch)
+    _Float16 *const ap_s = reinterpret_cast<_Float16 *>(h1_s);          // [2 planes][16][HSH]
+    float xr[TR / NW][C1];
+#pragma unroll
+    for (int rr = 0; rr < TR / NW; ++rr) {
+        const int lr = wave * (TR / NW) + rr;
+#pragma unroll
+        for (int i = 0; i < C1; ++i) {
+            const int c = lane + 64 * i;
+            xr[rr][i] = c < H1 ? h1_s[lr * HS1 + c] + pb1[i] : 0.f;
+        }
+    }
+    if (img) __syncthreads();
 #pragma unroll
     for (int rr = 0; rr < TR / NW; ++rr) {
         const int lr = wave * (TR / NW) + rr, row = row0 + lr;
         float x[C1], s1 = 0.f;
 #pragma unroll
         for (int i = 0; i < C1; ++i) {
-            const int c = lane + 64 * i;
-            x[i] = c < H1 ? h1_s[lr * HS1 + c] + pb1[i] : 0.f;
+            x[i] = xr[rr][i];
             s1 += x[i];
         }
         const float mean = wave_sum64(s1) * (1.f / H1);
@@ -213,11 +280,21 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
             if (c < H1) {
                 const float xh = (x[i] - mean) * rstd;
                 const float h = fmaxf(fmaf(xh, pg1[i], pbe1[i]), 0.f);
-                h1_s[lr * HS1 + c] = h;
+                if (img) {
+                    const float hs = h * SXL;
+                    const _Float16 hh = (_Float16)hs;
+                    ap_s[lr * HSH + c] = hh;
+                    ap_s[TR * HSH + lr * HSH + c] = (_Float16)(hs - (float)hh);
+                } else {
+                    h1_s[lr * HS1 + c] = h;
+                }
                 if (sv.xh1 && row < n) {
                     sv.xh1[(size_t)row * H1 + c] = xh;
                     sv.h1[(size_t)row * H1 + c] = h;
                 }
+            } else if (img && c < K2P) {                   // K padding of the planes (inputs 400..415)
+                ap_s[lr * HSH + c] = (_Float16)0.f;
+                ap_s[TR * HSH + lr * HSH + c] = (_Float16)0.f;
             }
         }
     }
@@ -238,6 +315,57 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
         wreal[i] = wave + NW * i < NT2 && nn < H2;
         wrow[i] = W.w2 + (size_t)(wreal[i] ? nn : 0) * H1 + 4 * l4;
     }
+    if (img) {
+        // A = the planes (one ds_read_b128 per plane and k32 step), B = this wave's rows of the image's [n][k] half straight
+        // from L2 (16 B per plane, tile and step), three MFMAs per tile and step, small terms first; the fragments of the
+        // NEXT three steps are requested before the current three issue
+        const int nt = (NT2 - wave + NW - 1) / NW;         // tiles of this wave: 3 (waves 0..3) or 2
+        const _Float16 *ah = ap_s + l15 * HSH + 8 * l4;
+        const _Float16 *bh[MT2];
+#pragma unroll
+        for (int i = 0; i < MT2; ++i) bh[i] = W.img + ((size_t)min(wave + NW * i, NT2 - 1) * FW_STEPS * 64 + lane) * 8;
+        constexpr int NS = FW_STEPS, GU = 3, NGRP = (NS + GU - 1) / GU;
+        f16x8 bcur[GU][MT2][2], bnxt[GU][MT2][2];
+        auto load_group = [&](const int g, f16x8 (&dst)[GU][MT2][2]) {
+#pragma unroll
+            for (int u = 0; u < GU; ++u)
+#pragma unroll
+                for (int i = 0; i < MT2; ++i) {
+                    const int c = g * GU + u;
+                    if (c < NS && i < nt) {
+                        dst[u][i][0] = *reinterpret_cast<const f16x8 *>(bh[i] + 512 * c);
+                        dst[u][i][1] = *reinterpret_cast<const f16x8 *>(bh[i] + IMG_FWD + 512 * c);
+                    }
+                }
+        };
+        load_group(0, bcur);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+            if (g + 1 < NGRP) load_group(g + 1, bnxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int c = g * GU + u;
+                if (c < NS) {
+                    const f16x8 a_h = *reinterpret_cast<const f16x8 *>(ah + 32 * c);
+                    const f16x8 a_m = *reinterpret_cast<const f16x8 *>(ah + TR * HSH + 32 * c);
+#pragma unroll
+                    for (int i = 0; i < MT2; ++i) if (i < nt) acc2[i] = mfma_h(a_m, bcur[u][i][0], acc2[i]);
+#pragma unroll
+                    for (int i = 0; i < MT2; ++i) if (i < nt) acc2[i] = mfma_h(a_h, bcur[u][i][1], acc2[i]);
+#pragma unroll
+                    for (int i = 0; i < MT2; ++i) if (i < nt) acc2[i] = mfma_h(a_h, bcur[u][i][0], acc2[i]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < GU; ++u)
+#pragma unroll
+                for (int i = 0; i < MT2; ++i) { bcur[u][i][0] = bnxt[u][i][0]; bcur[u][i][1] = bnxt[u][i][1]; }
+        }
+#pragma unroll
+        for (int i = 0; i < MT2; ++i) acc2[i] *= UNSC_L;
+    } else {
     const float *arow = h1_s + l15 * HS1 + 4 * l4;
 #pragma unroll 5
     for (int c = 0; c < H1 / 16; ++c) {
@@ -257,6 +385,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
         for (int i = 0; i < MT2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[i].z, acc2[i], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < MT2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[i].w, acc2[i], 0, 0, 0);
+    }
     }
 
     STAMP(3);
@@ -342,7 +471,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_small(const int n, const float 
                                                    const float *__restrict__ action, const Weights W,
                                                    float *__restrict__ out, const Saved sv, float *__restrict__ dq_da,
                                                    float *__restrict__ z_state) {
-    __shared__ __attribute__((aligned(16))) float h1_s[TR * HS1];
+    __shared__ __attribute__((aligned(16))) float h1_s[H1S_FLOATS];
     __shared__ __attribute__((aligned(16))) float z_s[TR * DS];
     fwd_small_body<CRITIC>(n, obs, action, W, out, sv, dq_da, z_state, h1_s, z_s, blockIdx.x * TR);
 }
@@ -364,7 +493,7 @@ struct FwdJobs {
     int n, blocks_per_job;
 };
 __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
-    __shared__ __attribute__((aligned(16))) float h1_s[TR * HS1];
+    __shared__ __attribute__((aligned(16))) float h1_s[H1S_FLOATS];
     __shared__ __attribute__((aligned(16))) float z_s[TR * DS];
     const int job = blockIdx.x / J.blocks_per_job, row0 = (blockIdx.x - job * J.blocks_per_job) * TR;
     const FwdJob &q = J.j[job];
@@ -406,8 +535,12 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
                                               const float *__restrict__ d_out, const float *__restrict__ out,
                                               const float *__restrict__ y, const float *__restrict__ aux,
                                               const Weights &W, const Saved &sv, const BwdOut &o, const TdIn &td,
-                                              float *__restrict__ dx2_s, float *__restrict__ red, const int row0) {
-    // dx2_s [16][308]: A operand of phase B; red [NW][16]: cross-wave reductions
+                                              float *__restrict__ dx2_s, float *__restrict__ red, float *__restrict__ rsc_s,
+                                              const int row0) {
+    // dx2_s [16][308]: A operand of phase B (with an fc2 image: its two f16 planes [2][16][328], each row scaled by a power
+    // of two whose inverse / 64 goes to rsc_s [16]); red [NW][16]: cross-wave reductions
+    const bool img = W.img != nullptr;                     // (uniform over the launch)
+    _Float16 *const dxp_s = reinterpret_cast<_Float16 *>(dx2_s);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     STAMP(8);
     // ---- phase A: head, ReLU and LayerNorm2 backward; wave w owns rows 2w, 2w+1; lanes stride the 300 columns.
@@ -490,17 +623,37 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
         }
         s1 = wave_sum64(s1) * (1.f / H2);
         s2 = wave_sum64(s2) * (1.f / H2);
+        float vv[C2];
 #pragma unroll
         for (int i = 0; i < C2; ++i) {
             const int c = lane + 64 * i;
-            if (c < DS) {
-                float v = 0.f;
-                if (c < H2 && ok) {
-                    v = rs[rr] * (dxh[i] - s1 - xh[rr][i] * s2);
-                    o.dx2[(size_t)row * H2 + c] = v;
-                }
-                dx2_s[lr * DS + c] = v;                     // zero in the K padding (columns 300..307)
+            float v = 0.f;
+            if (c < H2 && ok) {
+                v = rs[rr] * (dxh[i] - s1 - xh[rr][i] * s2);
+                o.dx2[(size_t)row * H2 + c] = v;
             }
+            vv[i] = v;
+            if (!img && c < DS) dx2_s[lr * DS + c] = v;     // zero in the K padding (columns 300..307)
+        }
+        if (img) {
+            // the row as two f16 planes, scaled by the power of two that puts its largest entry in [2^12, 2^13): gradients
+            // are far below f16's normal range as they come
+            float mx = 0.f;
+#pragma unroll
+            for (int i = 0; i < C2; ++i) mx = fmaxf(mx, fabsf(vv[i]));
+            mx = wave_max64(mx);
+            const int e = (__builtin_bit_cast(int, mx) >> 23) & 0xff;
+            const int se = min(max(266 - e, 1), 253);
+            const float sc = __builtin_bit_cast(float, se << 23), inv = __builtin_bit_cast(float, (254 - se) << 23);
+#pragma unroll
+            for (int i = 0; i < C2; ++i) {                  // c < 320: every plane entry, zeros beyond column 299
+                const int c = lane + 64 * i;
+                const float hs = vv[i] * sc;
+                const _Float16 hh = (_Float16)hs;
+                dxp_s[lr * DSH + c] = hh;
+                dxp_s[TR * DSH + lr * DSH + c] = (_Float16)(hs - (float)hh);
+            }
+            if (lane == 0) rsc_s[lr] = inv * (1.f / SWL);
         }
         if (lane == 0 && ok) o.dpre[row] = dpre;
     }
@@ -526,7 +679,51 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
         xv[r] = ok ? *reinterpret_cast<const float4 *>(sv.xh1 + (size_t)row * H1 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
         rs1[r] = ok ? sv.rstd1[row] : 0.f;
     }
-    if (wave < NG) {
+    if (img && wave < NG) {
+        // the image's backward half: this wave's four tiles (= its 64-column group) in k32 steps over n; A = the dX2 planes
+        const _Float16 *ah = dxp_s + l15 * DSH + 8 * l4;
+        const _Float16 *bh = W.img + 2 * IMG_FWD + ((size_t)wave * 4 * BW_STEPS * 64 + lane) * 8;
+        constexpr int GU = 2, NGRP = BW_STEPS / GU;
+        f16x8 bcur[GU][4][2], bnxt[GU][4][2];
+        auto load_group = [&](const int g, f16x8 (&dst)[GU][4][2]) {
+#pragma unroll
+            for (int u = 0; u < GU; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    dst[u][t][0] = *reinterpret_cast<const f16x8 *>(bh + (size_t)(t * BW_STEPS + g * GU + u) * 512);
+                    dst[u][t][1] = *reinterpret_cast<const f16x8 *>(bh + IMG_T + (size_t)(t * BW_STEPS + g * GU + u) * 512);
+                }
+        };
+        load_group(0, bcur);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+            if (g + 1 < NGRP) load_group(g + 1, bnxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int c = g * GU + u;
+                const f16x8 a_h = *reinterpret_cast<const f16x8 *>(ah + 32 * c);
+                const f16x8 a_m = *reinterpret_cast<const f16x8 *>(ah + TR * DSH + 32 * c);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = mfma_h(a_m, bcur[u][t][0], acc[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = mfma_h(a_h, bcur[u][t][1], acc[t]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = mfma_h(a_h, bcur[u][t][0], acc[t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < GU; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { bcur[u][t][0] = bnxt[u][t][0]; bcur[u][t][1] = bnxt[u][t][1]; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float back = rsc_s[l4 * 4 + r];          // 1 / (the row's scale * 64)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t][r] *= back;
+        }
+    } else if (wave < NG) {
         const float *arow = dx2_s + l15 * DS + 4 * l4;
         const float *wcol = W.w2 + (gok ? c0 : 0);
         // software pipeline as in the forward's layer 2: the fc2 rows of the NEXT group of 3 k16 steps are requested before
@@ -613,9 +810,10 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows(const int n, const int mod
                                                       const float *__restrict__ d_out, const float *__restrict__ out,
                                                       const float *__restrict__ y, const float *__restrict__ aux,
                                                       const Weights W, const Saved sv, const BwdOut o, const TdIn td) {
-    __shared__ __attribute__((aligned(16))) float dx2_s[TR * DS];
+    __shared__ __attribute__((aligned(16))) float dx2_s[DXS_FLOATS];
     __shared__ float red[NW * TR];
-    bwd_rows_body<CRITIC>(n, mode, scale, d_out, out, y, aux, W, sv, o, td, dx2_s, red, blockIdx.x * TR);
+    __shared__ float rsc_s[TR];
+    bwd_rows_body<CRITIC>(n, mode, scale, d_out, out, y, aux, W, sv, o, td, dx2_s, red, rsc_s, blockIdx.x * TR);
 }
 
 // The critic's per-row backward (TD prologue, mode 1) and the ACTOR's unit backward (mode 3) in one launch, on different
@@ -628,14 +826,15 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows_pair(const int n, const fl
                                                            const Weights Wc, const Saved sv_c, const BwdOut o_c, const TdIn td,
                                                            const float *__restrict__ mu_out, const Weights Wa, const Saved sv_a,
                                                            const BwdOut o_a) {
-    __shared__ __attribute__((aligned(16))) float dx2_s[TR * DS];
+    __shared__ __attribute__((aligned(16))) float dx2_s[DXS_FLOATS];
     __shared__ float red[NW * TR];
+    __shared__ float rsc_s[TR];
     const int nb = (n + TR - 1) / TR;
     if ((int)blockIdx.x < nb) {
-        bwd_rows_body<true>(n, 1, scale_c, nullptr, q_out, nullptr, nullptr, Wc, sv_c, o_c, td, dx2_s, red, blockIdx.x * TR);
+        bwd_rows_body<true>(n, 1, scale_c, nullptr, q_out, nullptr, nullptr, Wc, sv_c, o_c, td, dx2_s, red, rsc_s, blockIdx.x * TR);
     } else {
         const TdIn none{};
-        bwd_rows_body<false>(n, 3, 1.f, nullptr, mu_out, nullptr, nullptr, Wa, sv_a, o_a, none, dx2_s, red,
+        bwd_rows_body<false>(n, 3, 1.f, nullptr, mu_out, nullptr, nullptr, Wa, sv_a, o_a, none, dx2_s, red, rsc_s,
                              ((int)blockIdx.x - nb) * TR);
     }
 }
@@ -647,15 +846,16 @@ __global__ __launch_bounds__(64 * NW) void k_actor_rows(const int n, const float
                                                     const float *__restrict__ mu, const Weights Wc, float *__restrict__ q_out,
                                                     float *__restrict__ dq_da, const Weights Wa, const Saved sv_actor,
                                                     const BwdOut o) {
-    __shared__ __attribute__((aligned(16))) float tile[TR * HS1];       // the forward's h1 tile
-    __shared__ __attribute__((aligned(16))) float tile2[TR * DS];       // the forward's fc2 tile, then the backward's dX2 tile
+    __shared__ __attribute__((aligned(16))) float tile[H1S_FLOATS];     // the forward's h1 tile
+    __shared__ __attribute__((aligned(16))) float tile2[DXS_FLOATS];    // the forward's fc2 tile, then the backward's dX2 tile
     __shared__ float red[NW * TR];
+    __shared__ float rsc_s[TR];
     const int row0 = blockIdx.x * TR;
     const Saved none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     fwd_small_body<true>(n, obs, mu, Wc, q_out, none, dq_da, nullptr, tile, tile2, row0);
     __syncthreads();                                   // dq_da of these rows (global) and the tiles are handed over
     const TdIn td{};
-    bwd_rows_body<false>(n, 2, scale, nullptr, mu, nullptr, dq_da, Wa, sv_actor, o, td, tile2, red, row0);
+    bwd_rows_body<false>(n, 2, scale, nullptr, mu, nullptr, dq_da, Wa, sv_actor, o, td, tile2, red, rsc_s, row0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -675,6 +875,7 @@ struct AdamFused {
     const long long *step_dev;
     float lr, beta1, beta2, eps, weight_decay, tau;
     int on;
+    _Float16 *img_p, *img_t;      // fc2 images of the network / its target that this step keeps current (or nullptr)
 };
 
 struct AdamElem { float p, m, v, tg; };
@@ -683,9 +884,9 @@ __device__ __forceinline__ AdamElem adam_load(const AdamFused &A, const int t, c
     return AdamElem{A.p[t][i], A.m[t][i], A.v[t][i], A.tgt[t] ? A.tgt[t][i] : 0.f};
 }
 
-// k_adam_soft's arithmetic on one element already loaded
-__device__ __forceinline__ void adam_finish(const AdamFused &A, const int t, const size_t i, const float grad, AdamElem e,
-                                            const float bc1, const float sqrt_bc2) {
+// k_adam_soft's arithmetic on one element already loaded; returns {new parameter, new target}
+__device__ __forceinline__ float2 adam_finish(const AdamFused &A, const int t, const size_t i, const float grad, AdamElem e,
+                                              const float bc1, const float sqrt_bc2) {
     const float g = fmaf(A.weight_decay, e.p, grad);
     const float m = fmaf(A.beta1, e.m, (1.f - A.beta1) * g);
     const float v = fmaf(A.beta2, e.v, (1.f - A.beta2) * g * g);
@@ -694,7 +895,12 @@ __device__ __forceinline__ void adam_finish(const AdamFused &A, const int t, con
     const float denom = sqrtf(v) / sqrt_bc2 + A.eps;
     const float p = e.p - (A.lr / bc1) * (m / denom);
     A.p[t][i] = p;
-    if (A.tgt[t]) A.tgt[t][i] = fmaf(A.tau, p - e.tg, e.tg);
+    float tg = e.tg;
+    if (A.tgt[t]) {
+        tg = fmaf(A.tau, p - e.tg, e.tg);
+        A.tgt[t][i] = tg;
+    }
+    return make_float2(p, tg);
 }
 
 __device__ __forceinline__ void adam_apply(const AdamFused &A, const int t, const size_t i, const float grad,
@@ -797,7 +1003,12 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
                 if (jr < H2) {
                     const float g = ((p0[r] + p1[r]) + p2[r]) + p3[r];
                     G.w2[(size_t)jr * H1 + col] = g;
-                    if (A.on) adam_finish(A, 4, (size_t)jr * H1 + col, g, el[r], bc1, sqrt_bc2);
+                    if (A.on) {
+                        const float2 pt = adam_finish(A, 4, (size_t)jr * H1 + col, g, el[r], bc1, sqrt_bc2);
+                        // the element's pieces in the fc2 images the learn() kernels read instead of w2
+                        if (A.img_p) img_store(A.img_p, jr, col, pt.x, true);
+                        if (A.img_t && A.tgt[4]) img_store(A.img_t, jr, col, pt.y, false);
+                    }
                 }
             }
         }
@@ -933,6 +1144,7 @@ struct AdamTable {
     const float *g[MAXT];
     int numel[MAXT], block_start[MAXT + 1];
     int count;
+    _Float16 *img_p, *img_t;      // fc2 images kept current for tensor 4 (w2 [300,400]) and its target (or nullptr)
 };
 
 __global__ __launch_bounds__(256) void k_adam_soft(const AdamTable T, const long long *__restrict__ step_dev,
@@ -953,10 +1165,25 @@ __global__ __launch_bounds__(256) void k_adam_soft(const AdamTable T, const long
     const float denom = sqrtf(v) / sqrtf(bc2) + eps;
     p -= (lr / bc1) * (m / denom);
     T.p[ti][i] = p;
+    float tg = 0.f;
     if (T.tgt[ti]) {
-        const float tg = T.tgt[ti][i];
-        T.tgt[ti][i] = fmaf(tau, p - tg, tg);
+        tg = T.tgt[ti][i];
+        tg = fmaf(tau, p - tg, tg);
+        T.tgt[ti][i] = tg;
     }
+    if (ti == 4 && (T.img_p || T.img_t)) {
+        const int nn = i / H1, k = i - nn * H1;
+        if (T.img_p) img_store(T.img_p, nn, k, p, true);
+        if (T.img_t && T.tgt[ti]) img_store(T.img_t, nn, k, tg, false);
+    }
+}
+
+// the image of fc2 from scratch (tt_mlp_fc2_image_pack): one thread per weight; the padding of the buffer is never written
+__global__ __launch_bounds__(256) void k_img_pack(const float *__restrict__ w2, _Float16 *__restrict__ img) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H2 * H1) return;
+    const int nn = i / H1, k = i - nn * H1;
+    img_store(img, nn, k, w2[i], true);
 }
 
 // y = r + gamma * q' * (1 - done) (DDPG_agent.py:89-93) and the learn-step counter
@@ -1001,7 +1228,8 @@ __global__ __launch_bounds__(256) void k_head_td(const int n, const float *__res
 }
 
 Weights to_weights(const tt_mlp_weights *w) {
-    return Weights{w->w1, w->b1, w->g1, w->be1, w->w2, w->b2, w->g2, w->be2, w->w3, w->b3, w->wa, w->ba};
+    return Weights{w->w1, w->b1, w->g1, w->be1, w->w2, w->b2, w->g2, w->be2, w->w3, w->b3, w->wa, w->ba,
+                   reinterpret_cast<const _Float16 *>(w->fc2_img)};
 }
 
 bool ok_shape(const tt_mlp_weights *w, bool critic) {
@@ -1175,7 +1403,7 @@ int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *ac
                             const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const float *row_dq_da, const float *row_mu,
                             float row_scale, int count, float *const *params, float *const *exp_avg, float *const *exp_avg_sq,
                             float *const *targets, const int64_t *step_dev, float lr, float beta1, float beta2, float eps,
-                            float weight_decay, float tau, tt_stream_t stream) {
+                            float weight_decay, float tau, const tt_fc2_images *images, tt_stream_t stream) {
     if (n <= 0 || !obs || (critic && !action) || !saved_ok(saved) || !ws_ok(ws) || !ok_shape(grads, critic != 0) ||
         ((row_dq_da == nullptr) != (row_mu == nullptr)))
         return TT_EINVAL;
@@ -1189,6 +1417,10 @@ int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *ac
         A.step_dev = reinterpret_cast<const long long *>(step_dev);
         A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.weight_decay = weight_decay; A.tau = tau;
         A.on = 1;
+        if (images) {
+            A.img_p = reinterpret_cast<_Float16 *>(images->net);
+            A.img_t = reinterpret_cast<_Float16 *>(images->target);
+        }
     }
     const Saved sv{saved->xh1, saved->h1, saved->xh2, saved->h2, saved->rstd1, saved->rstd2};
     const BwdOut o{ws->dpre, ws->dz, ws->dx2, ws->dy1, ws->dx1};
@@ -1205,9 +1437,15 @@ int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *ac
 
 int tt_adam_soft_update(int count, float *const *params, const float *const *grads, float *const *exp_avg,
                         float *const *exp_avg_sq, float *const *targets, const int32_t *numel, const int64_t *step_dev,
-                        float lr, float beta1, float beta2, float eps, float weight_decay, float tau, tt_stream_t stream) {
+                        float lr, float beta1, float beta2, float eps, float weight_decay, float tau,
+                        const tt_fc2_images *images, tt_stream_t stream) {
     if (count <= 0 || count > MAXT || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !step_dev) return TT_EINVAL;
     AdamTable T{};
+    if (images && (images->net || images->target)) {       // tensors must then be in tt_mlp_weights order: w2 is number 4
+        if (count < 5 || numel[4] != H2 * H1) return TT_EINVAL;
+        T.img_p = reinterpret_cast<_Float16 *>(images->net);
+        T.img_t = reinterpret_cast<_Float16 *>(images->target);
+    }
     T.count = count;
     int blocks = 0;
     for (int i = 0; i < count; ++i) {
@@ -1221,6 +1459,15 @@ int tt_adam_soft_update(int count, float *const *params, const float *const *gra
     T.block_start[count] = blocks;
     hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, stream, T, reinterpret_cast<const long long *>(step_dev), lr,
                        beta1, beta2, eps, weight_decay, tau);
+    return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+uint64_t tt_mlp_fc2_image_bytes(void) { return (uint64_t)IMG_HALVES * 2; }
+
+int tt_mlp_fc2_image_pack(const tt_mlp_weights *w, tt_stream_t stream) {
+    if (!w || !w->w2 || !w->fc2_img || w->fc1_dims != H1 || w->fc2_dims != H2) return TT_EINVAL;
+    hipLaunchKernelGGL(k_img_pack, dim3((H2 * H1 + 255) / 256), dim3(256), 0, stream, w->w2,
+                       reinterpret_cast<_Float16 *>(w->fc2_img));
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 

@@ -65,13 +65,24 @@ class _NetState:
 
 
 class FusedLearner:
-    def __init__(self, agent, batch_size):
+    def __init__(self, agent, batch_size, fc2_images=None):
+        """fc2_images (None = on unless TT_LEARN_F32=1): the 400 x 300 products of learn() on the f16 MFMA from pre-split
+        images of the four networks' fc2 (include/ttenv.h: tt_mlp_weights.fc2_img) that the optimizer launches keep current;
+        off = every product on the exact-f32 MFMA straight from the weights."""
+        import os
         assert fused.supported(agent.actor) and fused.supported(agent.critic)
         self.agent, self.B = agent, int(batch_size)
         dev = self.dev = agent.actor.fc1.weight.device
         self.lib = L.load()
         self.critic = _NetState(agent.critic, agent.target_critic, self.B, dev)
         self.actor = _NetState(agent.actor, agent.target_actor, self.B, dev)
+        self.use_images = (os.environ.get("TT_LEARN_F32") != "1") if fc2_images is None else bool(fc2_images)
+        # this learner's own weight structs of the four networks (the module-level ones of fused.weights_of serve inference)
+        self._wstruct, self._img, self._img_seen = {}, {}, {}
+        for net in (agent.actor, agent.critic, agent.target_actor, agent.target_critic):
+            self._make_weights(net)
+        for st in (self.actor, self.critic):
+            st.images = L.TTFc2Images(net=self._img_ptr(st.net), target=self._img_ptr(st.target)) if self.use_images else None
         f = dict(dtype=torch.float32, device=dev)
         B = self.B
         self.ws_t = dict(dpre=torch.empty(B, **f), dz=torch.empty((B, 300), **f), dx2=torch.empty((B, 300), **f),
@@ -88,18 +99,71 @@ class FusedLearner:
         self.hyp_actor = (ga["lr"], ga["betas"][0], ga["betas"][1], ga["eps"], ga["weight_decay"])
         self.hyp_critic = (gc["lr"], gc["betas"][0], gc["betas"][1], gc["eps"], gc["weight_decay"])
 
+    # ------------------------------------------------------------------------------------------------- fc2 images
+    def _make_weights(self, net):
+        w = fused._fill_weights(net, L.TTMlpWeights())
+        if self.use_images:
+            img = torch.zeros(int(self.lib.tt_mlp_fc2_image_bytes()), dtype=torch.uint8, device=self.dev)   # padding stays zero
+            self._img[id(net)] = img
+            w.fc2_img = img.data_ptr()
+        self._wstruct[id(net)] = (tuple(p.data_ptr() for p in net.parameters()), w)
+        self._img_seen[id(net)] = None
+
+    def _img_ptr(self, net):
+        t = self._img.get(id(net))
+        return None if t is None else t.data_ptr()
+
+    def w(self, net):
+        """The learner's tt_mlp_weights of one of its four networks (with the fc2 image when images are on)."""
+        key, w = self._wstruct[id(net)]
+        if key != tuple(p.data_ptr() for p in net.parameters()):      # parameter storage replaced: rebuild
+            self._make_weights(net)
+            for st in (self.actor, self.critic):
+                if self.use_images:
+                    st.images = L.TTFc2Images(net=self._img_ptr(st.net), target=self._img_ptr(st.target))
+            w = self._wstruct[id(net)][1]
+        return w
+
+    def images_current(self):
+        """Have the four fc2 tensors been left alone by everything but this learner's own launches since their images were
+        made?  (torch counts in-place writes per tensor; the learner's kernels update weights AND images together.)"""
+        if not self.use_images:
+            return True
+        ag = self.agent
+        return all(self._img_seen[id(n)] == (n.fc2.weight._version, n.fc2.weight.data_ptr())
+                   for n in (ag.actor, ag.critic, ag.target_actor, ag.target_critic))
+
+    def refresh_images(self, force=False):
+        """(Re)make the image of every network whose fc2 was written by anyone else -- load_state_dict, a torch optimizer,
+        the hard target copy -- since the last look.  Called at the top of every eager learn step; a loop that replays
+        captured graphs calls it before it replays (DDPGRollout.run)."""
+        if not self.use_images:
+            return
+        ag = self.agent
+        for n in (ag.actor, ag.critic, ag.target_actor, ag.target_critic):
+            seen = (n.fc2.weight._version, n.fc2.weight.data_ptr())
+            if force or self._img_seen[id(n)] != seen:
+                L.check(self.lib.tt_mlp_fc2_image_pack(C.byref(self.w(n)), self._stream()))
+                self._img_seen[id(n)] = seen
+
     # -------------------------------------------------------------------------------------------------
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
+    def _fresh(self):
+        if self.use_images and not torch.cuda.is_current_stream_capturing():
+            self.refresh_images()          # (a capture holds launches only: its owner looks before it replays)
+
     def _fwd(self, net, obs, action, out, saved=None, dq_da=None):
+        self._fresh()
         L.check(self.lib.tt_mlp_forward_save(self.B, 1 if action is not None else 0, _p(obs), _p(action),
-                                             C.byref(fused.weights_of(net)), _p(out), C.byref(saved) if saved else None,
+                                             C.byref(self.w(net)), _p(out), C.byref(saved) if saved else None,
                                              _p(dq_da), self._stream()))
 
     def _bwd(self, st, mode, scale, obs, action, out, y=None, aux=None, td=None, dq=None):
+        self._fresh()
         L.check(self.lib.tt_mlp_backward(self.B, 1 if st.critic else 0, mode, float(scale), _p(obs), _p(action), None,
-                                         _p(out), _p(y), _p(aux), C.byref(fused.weights_of(st.net)), C.byref(st.saved),
+                                         _p(out), _p(y), _p(aux), C.byref(self.w(st.net)), C.byref(st.saved),
                                          C.byref(self.ws), C.byref(st.gstruct), C.byref(td) if td is not None else None,
                                          C.byref(dq) if dq is not None else None, self._stream()))
 
@@ -107,16 +171,19 @@ class FusedLearner:
         """_bwd + _adam in the backward's own two launches (include/ttenv.h: tt_mlp_backward_adam)."""
         lr, b1, b2, eps, wd = hyp
         L.check(self.lib.tt_mlp_backward_adam(self.B, 1 if st.critic else 0, mode, float(scale), _p(obs), _p(action), None,
-                                              _p(out), _p(y), _p(aux), C.byref(fused.weights_of(st.net)),
+                                              _p(out), _p(y), _p(aux), C.byref(self.w(st.net)),
                                               C.byref(st.saved), C.byref(self.ws), C.byref(st.gstruct), st.count, st.a_p,
                                               st.a_m, st.a_v, st.a_t, _p(self.step_dev), lr, b1, b2, eps, wd, tau,
                                               C.byref(td) if td is not None else None,
                                               C.byref(dq) if dq is not None else None, self._stream()))
+        if self.use_images:            # this (older) entry point does not maintain images: make them again before the next use
+            self._img_seen[id(st.net)] = self._img_seen[id(st.target)] = None
 
     def _adam(self, st, hyp, tau):
         lr, b1, b2, eps, wd = hyp
         L.check(self.lib.tt_adam_soft_update(st.count, st.a_p, st.a_g, st.a_m, st.a_v, st.a_t, st.a_n, _p(self.step_dev),
-                                             lr, b1, b2, eps, wd, tau, self._stream()))
+                                             lr, b1, b2, eps, wd, tau, C.byref(st.images) if st.images is not None else None,
+                                             self._stream()))
 
     def enable_data_parallel(self, group=None):
         """Mean of the flat gradient buffers over the ranks at the reference's two optimizer sites (RCCL: one AVG
@@ -139,6 +206,7 @@ class FusedLearner:
     def phase_a(self, states, actions, rewards, states_, done_u8, fuse_adam, window_dev=None):
         """Forwards, TD target, critic backward (+ the critic's Adam/soft update in the same launch when fuse_adam)."""
         ag, B = self.agent, self.B
+        self._fresh()
         # DDPG_agent.py:85-93 and :87, :101.  Only the target critic's LAST step needs the target actor's action (it enters
         # after LayerNorm2, networks.py:62-66), so four passes run side by side -- target actor on s', the target critic's
         # state branch on s', Q(s,a), mu(s), each filling 16 of the 256 CUs -- and the critic's backward then finishes
@@ -153,22 +221,22 @@ class FusedLearner:
                 (ag.critic, 1, states, actions, self.q, self.critic.saved, None),
                 (ag.actor, 0, states, None, self.mu, self.actor.saved, None))):
             jobs[j].critic, jobs[j].obs, jobs[j].action = crit, ptr(obs), ptr(act)
-            jobs[j].w, jobs[j].out = C.pointer(fused.weights_of(net)), ptr(out)
+            jobs[j].w, jobs[j].out = C.pointer(self.w(net)), ptr(out)
             jobs[j].saved = C.pointer(saved) if saved is not None else None
             jobs[j].dq_da, jobs[j].z_state = None, ptr(zst)
         L.check(self.lib.tt_mlp_forward_multi(B, 4, jobs, self._stream()))
         # critic step (DDPG_agent.py:95-98); its backward launch first finishes q'(s', mu'(s')) and the TD target for its
         # rows (tt_td_input: what tt_critic_head_td does as a launch of its own)
         td = L.TTTdInput(z_state=self.z_t.data_ptr(), mu_target=self.mu_t.data_ptr(),
-                         target_critic=C.pointer(fused.weights_of(ag.target_critic)), reward=rewards.data_ptr(),
+                         target_critic=C.pointer(self.w(ag.target_critic)), reward=rewards.data_ptr(),
                          done=done_u8.data_ptr(), gamma=float(ag.gamma), y_out=self.y.data_ptr(),
                          q_out=self.q_t.data_ptr(), step_dev=self.step_dev.data_ptr(),
                          window_dev=window_dev.data_ptr() if window_dev is not None else None)
         # ... and, on other workgroups of the same launch, the ACTOR's per-row backward for a unit gradient: it is linear in
         # the row's d(loss)/d(pre-tanh), which needs the updated critic and is applied in phase_b (include/ttenv.h)
-        L.check(self.lib.tt_mlp_backward_rows_pair(B, 2.0 / B, _p(self.q), C.byref(fused.weights_of(ag.critic)),
+        L.check(self.lib.tt_mlp_backward_rows_pair(B, 2.0 / B, _p(self.q), C.byref(self.w(ag.critic)),
                                                    C.byref(self.critic.saved), C.byref(self.ws), C.byref(td), _p(self.mu),
-                                                   C.byref(fused.weights_of(ag.actor)), C.byref(self.actor.saved),
+                                                   C.byref(self.w(ag.actor)), C.byref(self.actor.saved),
                                                    C.byref(self.ws_actor), self._stream()))
         self._weights(self.critic, self.hyp_critic, ag.tau, states, actions, self.ws, adam=fuse_adam)
 
@@ -179,6 +247,7 @@ class FusedLearner:
         L.check(self.lib.tt_mlp_backward_weights(self.B, 1 if st.critic else 0, _p(obs), _p(action), C.byref(st.saved), C.byref(ws),
                                                  C.byref(st.gstruct), _p(dq), _p(mu), float(sc), st.count if adam else 0,
                                                  st.a_p, st.a_m, st.a_v, st.a_t, _p(self.step_dev), lr, b1, b2, eps, wd, tau,
+                                                 C.byref(st.images) if (adam and st.images is not None) else None,
                                                  self._stream()))
 
     def phase_b(self, states, separate_adam):

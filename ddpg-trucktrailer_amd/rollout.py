@@ -187,6 +187,7 @@ class DDPGRollout:
         # that stream into the capture, and HIP's EndCapture then takes the PROCESS down (no exception to fall back from).
         if not self.use_graph or (self.dp and not self.dp_single_graph) or self.learner is None:   # (eager collectives)
             return self._learn_all()
+        self.learner.refresh_images()
         self._check_epoch()
         if self.graph is None:
             # The first calls run eagerly -- they ARE the updates of their vector steps, so a captured loop makes exactly
@@ -380,6 +381,8 @@ class DDPGRollout:
         """k vector steps, every one a graph replay once the loop is warm (4 eager steps) when whole-step graphs are on:
         the graph of graph_steps steps while that many remain, the single-step graph for the rest; eager step() otherwise."""
         ring = self.ring
+        if self.learner is not None:
+            self.learner.refresh_images()      # fc2 written by anyone but the learner's own launches since the last look?
         while k > 0:
             G = self.graph_steps
             if G and ring.k >= 4 and (self._graphs_current() or self._try_capture()):

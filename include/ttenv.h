@@ -229,7 +229,22 @@ typedef struct tt_mlp_weights {
                                re-pack and read nothing but the image, so the weights may be updated beside them */
     int32_t max_workgroups; /* > 0: the split kernel's workgroups (one per CU is resident) go out in consecutive grids of at most
                                this many, leaving the other CUs to launches on other streams; 0 = one grid */
+    void *fc2_img;          /* learn() kernels (tt_mlp_forward_save / _multi, tt_mlp_backward*): NULL = fc2 products on the exact-f32
+                               MFMA straight from w2; else a caller-owned device buffer of tt_mlp_fc2_image_bytes() bytes (zeroed
+                               once, then tt_mlp_fc2_image_pack) that holds w2 as pre-split f16 pieces in both orientations, and
+                               the products run on the f16 MFMA at f32 accuracy (three per block, as in the split-f16 forward).
+                               The CALLER keeps it equal to w2: optimizer steps through tt_mlp_backward_weights /
+                               tt_adam_soft_update with `images` rewrite every element they update; after any other change of
+                               w2 call tt_mlp_fc2_image_pack again. */
 } tt_mlp_weights;
+/* fc2 as pre-split f16 pieces (x64, h = rn16, m = rn16 of the remainder): [320][416] h, m (row = output neuron, the 400 inputs
+ * contiguous: forward products) then [400][320] h, m (row = input, the 300 outputs contiguous: dH1 = dX2 * W2); zero padding. */
+uint64_t tt_mlp_fc2_image_bytes(void);
+int tt_mlp_fc2_image_pack(const tt_mlp_weights *w, tt_stream_t stream);   /* w->fc2_img <- pieces of w->w2 */
+/* images an optimizer step keeps current (either may be NULL): the updated network's and its target's fc2_img */
+typedef struct tt_fc2_images {
+    void *net, *target;
+} tt_fc2_images;
 uint64_t tt_mlp_split_ws_bytes(void);
 /* Write the split kernel's image of `w` (fc2 and fc1 as pre-split f16 fragments, per-neuron vectors, head bias) into ws
  * (tt_mlp_split_ws_bytes() bytes).  bump (may be NULL): a device int64 that this launch increments by one -- the step
@@ -403,7 +418,7 @@ int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *ac
                             const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const float *row_dq_da, const float *row_mu,
                             float row_scale, int count, float *const *params, float *const *exp_avg, float *const *exp_avg_sq,
                             float *const *targets, const int64_t *step_dev, float lr, float beta1, float beta2, float eps,
-                            float weight_decay, float tau, tt_stream_t stream);
+                            float weight_decay, float tau, const tt_fc2_images *images /* may be NULL */, tt_stream_t stream);
 
 /* optimizer.step() of torch.optim.Adam (weight decay folded into the gradient; networks.py:49-50,133) for `count`
  * (<= 12) parameter tensors in one launch, then the soft update of the matching target tensors
@@ -411,7 +426,9 @@ int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *ac
  * pointers; *step_dev (device) is the 1-based count of this step. */
 int tt_adam_soft_update(int count, float *const *params, const float *const *grads, float *const *exp_avg,
                         float *const *exp_avg_sq, float *const *targets, const int32_t *numel, const int64_t *step_dev,
-                        float lr, float beta1, float beta2, float eps, float weight_decay, float tau, tt_stream_t stream);
+                        float lr, float beta1, float beta2, float eps, float weight_decay, float tau,
+                        const tt_fc2_images *images /* may be NULL; tensors in tt_mlp_weights order (w2 = index 4) */,
+                        tt_stream_t stream);
 
 /* target = rewards + gamma * critic_value_ with critic_value_[done] = 0 (DDPG_agent.py:89-93); also advances the
  * learn-step counter *step_dev (may be NULL) that tt_adam_soft_update reads. */

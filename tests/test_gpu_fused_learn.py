@@ -65,7 +65,9 @@ def _agent(dev, z, capturable=False):
     return a
 
 
-def test_fused_learn_matches_reference_fixture_and_torch_path(gpu_device):
+@pytest.mark.parametrize("images", [True, False])
+def test_fused_learn_matches_reference_fixture_and_torch_path(gpu_device, images):
+    """images: learn()'s 400x300 products on the f16 MFMA from pre-split fc2 images (the default) / on the exact-f32 MFMA."""
     import torch
     from conftest import GOLDEN
     from ddpg_trucktrailer_amd.fused_learn import FusedLearner
@@ -73,7 +75,8 @@ def test_fused_learn_matches_reference_fixture_and_torch_path(gpu_device):
     z = np.load(os.path.join(GOLDEN, "f5_learner.npz"), allow_pickle=False)
     fused_agent, torch_agent = _agent(gpu_device, z), _agent(gpu_device, z)
     s, a, r, s2, d = _batch(z, gpu_device)
-    fl = FusedLearner(fused_agent, 256)
+    fl = FusedLearner(fused_agent, 256, fc2_images=images)
+    assert fl.use_images == images
     d8 = d.to(torch.uint8)
     fl.learn_batch(s, a, r, s2, d8)
     torch_agent.learn_batch(s, a, r, s2, d)
@@ -97,7 +100,8 @@ def test_fused_learn_matches_reference_fixture_and_torch_path(gpu_device):
     assert int(fl2.step_dev.item()) == 3 and torch.equal(fl2.critic.m, fl.critic.m)
 
 
-def test_fused_gradients_and_losses_match_the_reference(gpu_device):
+@pytest.mark.parametrize("images", [True, False])
+def test_fused_gradients_and_losses_match_the_reference(gpu_device, images):
     """FusedLearner's flat gradient buffers (what RCCL all-reduces) at both optimizer sites of learn() steps 1..3 against
     the .grad the reference's own learn() held at its optimizer.step() calls (fixture F5 grad<i>/..., DDPG_agent.py:95-104),
     3e-5 relative to each tensor's largest gradient; critic loss from the fused q / y, actor loss from Q(s, mu(s))."""
@@ -109,7 +113,7 @@ def test_fused_gradients_and_losses_match_the_reference(gpu_device):
     agent = _agent(gpu_device, z)
     s, a, r, s2, d = _batch(z, gpu_device)
     d8 = d.to(torch.uint8)
-    fl = FusedLearner(agent, 256)
+    fl = FusedLearner(agent, 256, fc2_images=images)
 
     def named(st):
         head = "q" if st.critic else "mu"
@@ -207,3 +211,72 @@ def test_target_critic_in_two_pieces(gpu_device):
     assert (q - q_ref).abs().max().item() <= 1e-5 and (q - q_t).abs().max().item() <= 2e-5 * max(1.0, q_t.abs().max().item())
     assert (y - y_ref).abs().max().item() <= 1e-5 and int(step.item()) == 1
     assert torch.equal(y[done.bool()], r[done.bool()])               # critic_value_[done] = 0 (DDPG_agent.py:89)
+
+
+def test_fc2_images_follow_the_weights(gpu_device):
+    """The pre-split f16 images of fc2 (tt_mlp_weights.fc2_img) that learn()'s kernels read instead of w2: kept current by the
+    optimizer launches element by element (Adam inside the weight-gradient launch, and as its own launch after an
+    all-reduce), so after any number of steps they equal an image made from scratch, bit for bit; pieces h + m reproduce
+    64 w to 2^-22; a write to fc2 by anyone else (torch) is noticed and the image made again."""
+    import ctypes as C
+    import torch
+    from conftest import GOLDEN
+    from ddpg_trucktrailer_amd import _lib as L
+    from ddpg_trucktrailer_amd.fused_learn import FusedLearner
+    from test_learner import _batch
+    z = np.load(os.path.join(GOLDEN, "f5_learner.npz"), allow_pickle=False)
+    s, a, r, s2, d = _batch(z, gpu_device)
+    d8 = d.to(torch.uint8)
+    lib = L.load()
+    nbytes = int(lib.tt_mlp_fc2_image_bytes())
+    FWD, BWD = 20 * 13 * 512, 28 * 10 * 512            # halves per plane: MFMA fragments of 64 lanes x 8 halves (ttlearn.hip)
+    assert nbytes == 2 * 2 * (FWD + BWD)
+    nn, kk = np.meshgrid(np.arange(300), np.arange(400), indexing="ij")
+    fwd_idx = torch.tensor((((nn >> 4) * 13 + (kk >> 5)) * 64 + ((kk >> 3) & 3) * 16 + (nn & 15)) * 8 + (kk & 7), device=gpu_device)
+    tile = (kk >> 6) * 4 + (kk & 3)
+    bwd_idx = torch.tensor(((tile * 10 + (nn >> 5)) * 64 + ((nn >> 3) & 3) * 16 + ((kk >> 2) & 15)) * 8 + (nn & 7), device=gpu_device)
+
+    def scratch(fl, net):
+        w = L.TTMlpWeights()
+        C.memmove(C.byref(w), C.byref(fl.w(net)), C.sizeof(w))
+        img = torch.zeros(nbytes, dtype=torch.uint8, device=gpu_device)
+        w.fc2_img = img.data_ptr()
+        L.check(lib.tt_mlp_fc2_image_pack(C.byref(w), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return img
+
+    for dp_style in (False, True):
+        agent = _agent(gpu_device, z)
+        fl = FusedLearner(agent, 256, fc2_images=True)
+        if dp_style:                                   # separate Adam launches, as after a gradient all-reduce
+            fl.grad_sync_critic = fl.grad_sync_actor = lambda: None
+        for _ in range(4):
+            fl.learn_batch(s, a, r, s2, d8)
+        torch.cuda.synchronize()
+        assert fl.images_current()
+        for net in (agent.actor, agent.critic, agent.target_actor, agent.target_critic):
+            kept, fresh = fl._img[id(net)], scratch(fl, net)
+            halves = kept.view(torch.float16)
+            fwd = FWD
+            is_target = net in (agent.target_actor, agent.target_critic)
+            if is_target:                              # a target's image serves forwards only: its [k][n] half is not maintained
+                assert torch.equal(halves[:2 * fwd], fresh.view(torch.float16)[:2 * fwd]), "target image differs"
+            else:
+                assert torch.equal(kept, fresh), "maintained image differs from one made from scratch"
+            w2 = net.fc2.weight.detach()
+            hp, mp = halves[:FWD], halves[FWD:2 * FWD]
+            h, m = hp[fwd_idx].float(), mp[fwd_idx].float()
+            assert ((h + m) / 64 - w2).abs().max().item() <= 2 ** -22 * w2.abs().max().item()
+            rest = hp.clone(); rest[fwd_idx.reshape(-1)] = 0
+            assert not rest.any(), "padding of the forward plane is not zero"
+            if not is_target:                          # the backward orientation holds the same numbers
+                th = halves[2 * FWD:2 * FWD + BWD]
+                assert torch.equal(th[bwd_idx], hp[fwd_idx])
+                rest = th.clone(); rest[bwd_idx.reshape(-1)] = 0
+                assert not rest.any()
+        # someone else writes fc2: noticed, image made again before the next step
+        with torch.no_grad():
+            agent.critic.fc2.weight.mul_(1.01)
+        assert not fl.images_current()
+        fl.learn_batch(s, a, r, s2, d8)
+        assert fl.images_current()
+        assert torch.equal(fl._img[id(agent.critic)], scratch(fl, agent.critic))
