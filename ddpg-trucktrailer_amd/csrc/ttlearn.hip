@@ -989,6 +989,7 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
         const f32x4 p2 = *reinterpret_cast<const f32x4 *>(&part[2][wave][lane * 4]);
         const f32x4 p3 = *reinterpret_cast<const f32x4 *>(&part[3][wave][lane * 4]);
         const int col = grp * 64 + 4 * l15 + wave;                       // tile t holds columns c0 + t
+        float pnew[4] = {0.f, 0.f, 0.f, 0.f}, tnew[4] = {0.f, 0.f, 0.f, 0.f};      // updated parameter / target (0 = padding)
         if (col < H1 && grp * 64 + 4 * l15 < H1) {
             // the four elements' optimizer state first: the updates below store through pointers that may alias a later load
             AdamElem el[4];
@@ -1005,10 +1006,43 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
                     G.w2[(size_t)jr * H1 + col] = g;
                     if (A.on) {
                         const float2 pt = adam_finish(A, 4, (size_t)jr * H1 + col, g, el[r], bc1, sqrt_bc2);
-                        // the element's pieces in the fc2 images the learn() kernels read instead of w2
-                        if (A.img_p) img_store(A.img_p, jr, col, pt.x, true);
-                        if (A.img_t && A.tgt[4]) img_store(A.img_t, jr, col, pt.y, false);
+                        pnew[r] = pt.x; tnew[r] = pt.y;
                     }
+                }
+            }
+        }
+        if (A.on && (A.img_p || A.img_t)) {
+            // The block's 16 x 64 patch of fc2 in the images the learn() kernels read instead of w2 (fragment order, see
+            // IMG_FWD above): exactly two consecutive 1 KB fragments of each forward plane (rows = tile jt, k32 steps
+            // 2 grp, 2 grp + 1) and half a fragment (512 B) of each of the group's four backward tiles.  Pieces are staged
+            // in LDS in that order and leave as 16-byte stores; scattered 2-byte stores cost 10 us per launch.
+            _Float16 (*stage)[1024] = reinterpret_cast<_Float16 (*)[1024]>(&part[0][0][0]);      // 6 x 2 KB of the 16 KB
+            __syncthreads();                                              // every wave has read its partial sums
+            const int kq = 4 * l15 + wave;                                // column inside the group
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = l4 * 4 + r;                                // row inside the tile
+                const float sp = pnew[r] * SWL, st = tnew[r] * SWL;
+                const _Float16 ph = (_Float16)sp, pm = (_Float16)(sp - (float)ph), th = (_Float16)st, tm = (_Float16)(st - (float)th);
+                const int f = (kq >> 5) * 512 + (((kq >> 3) & 3) * 16 + lr) * 8 + (kq & 7);
+                const int b = wave * 256 + ((l4 >> 1) * 16 + l15) * 8 + (l4 & 1) * 4 + r;
+                stage[0][f] = ph; stage[1][f] = pm; stage[2][b] = ph; stage[3][b] = pm; stage[4][f] = th; stage[5][f] = tm;
+            }
+            __syncthreads();
+            const size_t fbase = (size_t)(jt * FW_STEPS + 2 * grp) * 512;
+            const int fcount = grp < NG - 1 ? 128 : 64;                   // the last group has one k32 step (columns 384..415)
+            for (int q = tid; q < 6 * 128; q += 256) {
+                const int arr = q >> 7, w = q & 127;
+                const uint4 v = *reinterpret_cast<const uint4 *>(&stage[arr][w * 8]);
+                if (arr == 2 || arr == 3) {
+                    if (A.img_p) {
+                        const size_t o = 2 * IMG_FWD + (arr == 3 ? IMG_T : 0) +
+                                         ((size_t)((grp * 4 + (w >> 5)) * BW_STEPS + (jt >> 1)) * 64 + (jt & 1) * 32) * 8 + (w & 31) * 8;
+                        *reinterpret_cast<uint4 *>(A.img_p + o) = v;
+                    }
+                } else if (w < fcount) {
+                    _Float16 *img = arr < 2 ? A.img_p : (A.tgt[4] ? A.img_t : nullptr);
+                    if (img) *reinterpret_cast<uint4 *>(img + ((arr & 1) ? IMG_FWD : 0) + fbase + w * 8) = v;
                 }
             }
         }

@@ -237,8 +237,9 @@ typedef struct tt_mlp_weights {
                                tt_adam_soft_update with `images` rewrite every element they update; after any other change of
                                w2 call tt_mlp_fc2_image_pack again. */
 } tt_mlp_weights;
-/* fc2 as pre-split f16 pieces (x64, h = rn16, m = rn16 of the remainder): [320][416] h, m (row = output neuron, the 400 inputs
- * contiguous: forward products) then [400][320] h, m (row = input, the 300 outputs contiguous: dH1 = dX2 * W2); zero padding. */
+/* fc2 as pre-split f16 pieces (x64, h = rn16, m = rn16 of the remainder) in MFMA-fragment order (1 KB = 64 lanes x 8 halves =
+ * one coalesced 16-byte load per lane): a forward half [20 neuron tiles][13 k32 steps] and a backward half (dH1 = dX2 * W2)
+ * [28 column tiles][10 k32 steps], an h and an m plane of each; zero padding (layout private to csrc/ttlearn.hip). */
 uint64_t tt_mlp_fc2_image_bytes(void);
 int tt_mlp_fc2_image_pack(const tt_mlp_weights *w, tt_stream_t stream);   /* w->fc2_img <- pieces of w->w2 */
 /* images an optimizer step keeps current (either may be NULL): the updated network's and its target's fc2_img */
