@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--repeats", type=int, default=5, help="extra hipEvent-timed repeats of the K steps after the timed region")
     ap.add_argument("--no-graph", action="store_true", help="launch everything eagerly (no hipGraphs)")
-    ap.add_argument("--step-graph", type=int, default=4, help="ddpg workload: whole vector steps per captured hipGraph "
+    ap.add_argument("--step-graph", type=int, default=20, help="ddpg workload: whole vector steps per captured hipGraph "
                     "(0: only learn() is captured)")
     ap.add_argument("--torch-learn", action="store_true", help="learn() through torch autograd instead of the fused HIP kernels")
     ap.add_argument("--serial", action="store_true", help="ddpg workload: the reference's strict order (policy, env step, then "
@@ -319,7 +319,7 @@ def main():
         workload = (f"{vname} N={n}/GPU + full DDPG learn() x{args.updates_per_step} per vector step (actor/critic 400x300, "
                     f"batch {args.batch}, OU noise, replay ring {args.replay_slots}xN) (BASELINE config {5 if variant else 3})")
         if loop.graph_steps:
-            launch = (f"every vector step a hipGraph replay: one graph of {loop.graph_steps} whole steps and one single-step graph "
+            launch = (f"every vector step a hipGraph replay: graphs of {loop.graph_steps}, 4 and 1 whole steps "
                       f"serve every ring position (device cursor)" + (" -- the two RCCL gradient all-reduces of a step are nodes of its graph"
                                                                if loop.dp else "") if not (loop.dp and not loop.dp_single_graph) else
                       "three hipGraph segments per step with the two RCCL gradient all-reduces between them")

@@ -166,12 +166,16 @@ class TrajectoryRing:
         return L.TTRingCursor(self.k_dev.data_ptr(), self.slots, 0, self.cursor_dev.data_ptr())
 
     def _batch_bufs(self, batch_size):
-        if getattr(self, "_bufs", None) is None or self._bufs[0].shape[0] != batch_size:
+        # one set per batch size, kept for the ring's lifetime: captured graphs hold these addresses, so a draw of another
+        # size must not free (and hand to someone else) the buffers a graph still writes
+        cache = self.__dict__.setdefault("_buf_cache", {})
+        if batch_size not in cache:
             f = dict(dtype=torch.float32, device=self.device)
             d = self.obs.shape[2]
-            self._bufs = (torch.empty((batch_size, d), **f), torch.empty((batch_size, 1), **f), torch.empty(batch_size, **f),
-                          torch.empty((batch_size, d), **f), torch.empty(batch_size, dtype=torch.uint8, device=self.device),
-                          torch.empty((batch_size, 2), dtype=torch.int32, device=self.device))
+            cache[batch_size] = (torch.empty((batch_size, d), **f), torch.empty((batch_size, 1), **f), torch.empty(batch_size, **f),
+                                 torch.empty((batch_size, d), **f), torch.empty(batch_size, dtype=torch.uint8, device=self.device),
+                                 torch.empty((batch_size, 2), dtype=torch.int32, device=self.device))
+        self._bufs = cache[batch_size]          # (the set of the latest draw)
         return self._bufs
 
     def sample_args(self, batch_size, seed=0, k_dev=None, reserve=0):

@@ -126,6 +126,7 @@ class DDPGRollout:
         self.graph_steps = int(graph_steps) if ok else 0
         if self.graph_steps and self.dp and not self.dp_single_graph:
             self.graph_steps = 1        # data-parallel: a step is three graphs with the two gradient all-reduces between
+        self.graphM = None              # four vector steps (only when graph_steps > 4)
         self.graph1 = None              # one vector step (data-parallel: up to the critic's gradient)
         self.graphG = None              # graph_steps vector steps (one rank)
         self.dp_graphs = None
@@ -164,7 +165,7 @@ class DDPGRollout:
 
     def _learn_once(self, u=0, presampled=False):
         if presampled:         # the step's opening launch already drew this batch into the ring's buffers
-            s, a, r, s2, d = self.ring._bufs[:5]
+            s, a, r, s2, d = self.ring._batch_bufs(self.batch_size)[:5]
         else:
             s, a, r, s2, d = self._sample(u)
         if self.learner is not None:
@@ -255,7 +256,7 @@ class DDPGRollout:
         # learn()'s branch is recorded first: with the policy's launches first the step takes 0.131 ms instead of 0.120
         with torch.cuda.stream(side):
             if dp_capture:
-                self.learner.phase_a(*self.ring._bufs[:5], fuse_adam=False,
+                self.learner.phase_a(*self.ring._batch_bufs(self.batch_size)[:5], fuse_adam=False,
                                      window_dev=self.k_pipe_dev if self.updates_per_step == 1 else None)
             elif learn:
                 self._learn_all(presampled=True)
@@ -283,7 +284,7 @@ class DDPGRollout:
         """Drop every captured graph (they bake kernel arguments by value: the env's reset seed, per-env-goal mode and
         pose pool, the ring's side-buffer count; ring and network addresses).  Called automatically when the env or the
         ring reports a change of those (env.graph_epoch, ring.side_epoch)."""
-        self.graph = self.graph1 = self.graphG = self.dp_graphs = None
+        self.graph = self.graph1 = self.graphG = self.graphM = self.dp_graphs = None
 
     def _check_epoch(self):
         epoch = (getattr(self.env, "graph_epoch", 0), self.ring.side_epoch)
@@ -320,11 +321,13 @@ class DDPGRollout:
         ring, G = self.ring, self.graph_steps
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
-        assert getattr(ring, "_bufs", None) is not None, "sample buffers must exist before a capture (run a step first)"
+        ring._batch_bufs(self.batch_size)       # (allocated before the capture; kept per batch size for the ring's lifetime)
         self.graph1 = self._capture(self._capture_body, side)
         self.graphG = self._capture(lambda: [self._capture_body() for _ in range(G)], side) if G > 1 else None
+        # a launch of a graph costs ~12 us whatever it holds: long graphs for the bulk, a 4-step one for what is left over
+        self.graphM = self._capture(lambda: [self._capture_body() for _ in range(4)], side) if G > 4 else None
         if self.dp and not self.dp_single_graph:
-            s = ring._bufs[0]
+            s = ring._batch_bufs(self.batch_size)[0]
             self.dp_graphs = {}
             pieces = {"b": lambda: self.learner.phase_b(s, separate_adam=True), "c": self.learner.phase_c}
             for u in range(1, self.updates_per_step):      # the further updates of a step: sample + up to the critic's gradient
@@ -392,6 +395,9 @@ class DDPGRollout:
                 elif G > 1 and k >= G:
                     self.graphG.replay()
                     done = G
+                elif self.graphM is not None and k >= 4:
+                    self.graphM.replay()
+                    done = 4
                 else:
                     self.graph1.replay()
                     done = 1

@@ -204,28 +204,31 @@ def test_run_is_all_graph_replays_for_any_warmup_and_steps(gpu_device, monkeypat
     from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
     n = 1024
     loops = []
-    for graph_steps in (4, 0):
+    for graph_steps in (4, 20, 0):
         env = TruckTrailerVecEnv(n)
         env.reset(seed=9)
         loops.append(DDPGRollout(env, batch_size=256, replay_slots=8, seed=9, use_graph=True, graph_steps=graph_steps))
-    a, b = loops
-    a.prepare()
-    assert a.ring.k == 4 and a.graph1 is not None and a.graphG is not None
+    a, a20, b = loops
 
     def no_eager():
         raise AssertionError("run() launched a vector step eagerly")
-    monkeypatch.setattr(a, "step", no_eager)
-    a.run(5)            # warm-up of 5: one 4-step graph + one single
-    a.run(20)           # five 4-step graphs -- from ring position 9 of 8 slots: the graphs are position-independent
-    a.run(3)
+    for lp in (a, a20):
+        lp.prepare()
+        assert lp.ring.k == 4 and lp.graph1 is not None and lp.graphG is not None
+        assert (lp.graphM is not None) == (lp.graph_steps > 4)      # bench.py's default: graphs of 20, 4 and 1 steps
+        monkeypatch.setattr(lp, "step", no_eager)
+        lp.run(5)            # warm-up of 5: one 4-step graph + one single
+        lp.run(20)           # five 4-step graphs / one 20-step graph -- from ring position 9 of 8 slots: position-independent
+        lp.run(3)
     for _ in range(4 + 5 + 20 + 3):
         b.step()
     torch.cuda.synchronize()
-    assert a.ring.k == b.ring.k == 32 and int(a.ring.k_dev.item()) == 32
-    assert torch.equal(_loop_flat(a), _loop_flat(b))
-    for name in ("obs", "act", "rew", "done"):
-        assert torch.equal(getattr(a.ring, name), getattr(b.ring, name)), name
-    assert torch.equal(a.env.state, b.env.state)
+    for lp in (a, a20):
+        assert lp.ring.k == b.ring.k == 32 and int(lp.ring.k_dev.item()) == 32
+        assert torch.equal(_loop_flat(lp), _loop_flat(b))
+        for name in ("obs", "act", "rew", "done"):
+            assert torch.equal(getattr(lp.ring, name), getattr(b.ring, name)), name
+        assert torch.equal(lp.env.state, b.env.state)
     for lp in loops:
         lp.env.close()
 

@@ -26,3 +26,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq -- python3 bench.py --serial --steps 20 --warmup 8 --step-graph 0 --no-cpu-baseline --repeats 0 > $out/pmc_sq.log 2>&1 || echo "SQ pass failed (see $out/pmc_sq.log)"
 find $out -name "*.csv" | head -40
+python3 tools/sweep.py > $out/sweep_env.md 2> $out/sweep_env.err
+bash tools/sweep_loop.sh > $out/sweep_loop.md 2> $out/sweep_loop.err
