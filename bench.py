@@ -314,6 +314,7 @@ def main():
                            graph_steps=args.step_graph, updates_per_step=args.updates_per_step,
                            pipeline=False if args.serial else None)
         loop.prepare()       # one-off work (4 untimed vector steps + graph capture) before warm-up and the timed region
+        loop.first_launches()   # ... and the first launch of every captured graph (it uploads the graph)
         ddpg_loop = loop
         run = loop.run       # every step a hipGraph replay (G-step graphs where aligned, single-step graphs elsewhere)
         workload = (f"{vname} N={n}/GPU + full DDPG learn() x{args.updates_per_step} per vector step (actor/critic 400x300, "
@@ -330,7 +331,7 @@ def main():
                  if loop.pipeline else "serial: policy, env step, then learn() on a window that includes the new step")
         extra = {"batch": args.batch, "updates_per_step": args.updates_per_step,
                  "replay_capacity": args.replay_slots * n, "launch": launch, "order": order,
-                 "env_steps_per_update": n / args.updates_per_step,
+                 "env_steps_per_update": n / args.updates_per_step, "setup_vector_steps": loop.vector_steps,
                  "note": ("throughput of the configuration BASELINE.json names; how the same loop trains at this and at other "
                           "update ratios (--updates-per-step): profiles/r02_training_behaviour.md")}
 

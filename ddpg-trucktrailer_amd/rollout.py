@@ -380,6 +380,15 @@ class DDPGRollout:
         if self.graph_steps and not self._graphs_current():
             self._try_capture()
 
+    def first_launches(self):
+        """Replay every captured graph once (its first launch uploads it: ~0.2 ms more than any later one), as part of the
+        setup: advances the loop by graph_steps (+ 4 when graph_steps > 4) + 1 vector steps.  Returns that number."""
+        if not (self.graph_steps and self._graphs_current()):
+            return 0
+        k = 1 if (self.dp and not self.dp_single_graph) else self.graph_steps + (4 if self.graphM is not None else 0) + 1
+        self.run(k)
+        return k
+
     def run(self, k):
         """k vector steps, every one a graph replay once the loop is warm (4 eager steps) when whole-step graphs are on:
         the graph of graph_steps steps while that many remain, the single-step graph for the rest; eager step() otherwise."""
