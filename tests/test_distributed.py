@@ -276,3 +276,18 @@ def test_bench_refuses_fewer_gpus_than_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 3), "--steps", "4", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "refusing" in r.stderr and "{" not in r.stdout
+
+
+def test_graph_collective_probe_says_no_without_a_working_child(monkeypatch):
+    """dp_probe.graph_collectives_ok(): any failure of the child -- here: no GPU, or (on a GPU box) a rendezvous that cannot
+    complete because only one of two ranks exists -- within the time limit means "no", and the caller is left alone."""
+    from ddpg_trucktrailer_amd.dp_probe import graph_collectives_ok
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    assert graph_collectives_ok(timeout=20.0) is False
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.delenv("TT_DP_PROBE_FORCE", raising=False)
+    assert graph_collectives_ok(timeout=20.0) is False          # one rank: nothing to ask
