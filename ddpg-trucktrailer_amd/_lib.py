@@ -35,7 +35,7 @@ class TTInfo(C.Structure):
 class TTMlpWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "w3", "b3", "wa", "ba")] + \
                [("in_dim", C.c_int32), ("fc1_dims", C.c_int32), ("fc2_dims", C.c_int32), ("capped_grids", C.c_int32),
-                ("split_ws", C.c_void_p), ("ws_packed", C.c_int32), ("max_workgroups", C.c_int32), ("fc2_img", C.c_void_p)]
+                ("split_ws", C.c_void_p), ("ws_packed", C.c_int32), ("max_workgroups", C.c_int32), ("split_ws_alt", C.c_void_p), ("fc2_img", C.c_void_p)]
 
 
 class TTFc2Images(C.Structure):
@@ -80,7 +80,8 @@ class TTSampleArgs(C.Structure):
     _fields_ = [("batch", C.c_int32), ("n_envs", C.c_int32), ("slots", C.c_int32), ("reserve", C.c_int32), ("k_dev", C.c_void_p),
                 ("obs", C.c_void_p), ("act", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p), ("seed", C.c_uint64),
                 ("side", C.POINTER(TTSideBuffer)), ("s_out", C.c_void_p), ("a_out", C.c_void_p), ("r_out", C.c_void_p),
-                ("s2_out", C.c_void_p), ("d_out", C.c_void_p), ("idx_out", C.c_void_p)]
+                ("s2_out", C.c_void_p), ("d_out", C.c_void_p), ("idx_out", C.c_void_p), ("lag", C.c_int32),
+                ("reserved_", C.c_int32)]
 
 
 class TTMlpBwdWs(C.Structure):
@@ -126,7 +127,7 @@ _SIGNATURES = {
     "tt_actor_forward": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_actor_act": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P, _U64, _U64, _P, C.c_float, C.c_float, C.c_float,
                                _P, _P, _P, _P]),
-    "tt_ring_sample": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _U64, _I, C.POINTER(TTSideBuffer), _P, _P, _P, _P, _P, _P, _P]),
+    "tt_ring_sample": (C.c_int, [_I, _I, _I, _P, _P, _P, _P, _P, _U64, _I, _I, C.POINTER(TTSideBuffer), _P, _P, _P, _P, _P, _P, _P]),
     "tt_critic_forward": (C.c_int, [_I, _P, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_mlp_forward_save": (C.c_int, [_I, _I, _P, _P, C.POINTER(TTMlpWeights), _P, C.POINTER(TTMlpSaved), _P, _P]),
     "tt_mlp_forward_multi": (C.c_int, [_I, _I, C.POINTER(TTFwdJob), _P]),

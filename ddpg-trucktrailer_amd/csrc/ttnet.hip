@@ -325,10 +325,10 @@ int tt_actor_act(int n, const float *obs, const tt_mlp_weights *w, float *ou_sta
 }
 
 static int make_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const float *obs, const float *act,
-                       const float *rew, const uint8_t *done, uint64_t seed, int reserve, const tt_side_buffer *side,
+                       const float *rew, const uint8_t *done, uint64_t seed, int reserve, int lag, const tt_side_buffer *side,
                        float *s_out, float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out,
                        RingSample &R) {
-    if (batch < 0 || n_envs <= 0 || reserve < 0 || slots < 3 + reserve || !k_dev || !obs || !act || !rew || !done || !s_out ||
+    if (batch < 0 || n_envs <= 0 || reserve < 0 || lag < 0 || slots < 3 + reserve || !k_dev || !obs || !act || !rew || !done || !s_out ||
         !a_out || !r_out || !s2_out || !d_out)
         return TT_EINVAL;
     SideBuf sb{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
@@ -336,7 +336,7 @@ static int make_sample(int batch, int n_envs, int slots, const int64_t *k_dev, c
         if (!side->obs || !side->act || !side->rew || !side->obs2 || !side->done) return TT_EINVAL;
         sb = SideBuf{side->obs, side->act, side->rew, side->obs2, side->done, side->count};
     }
-    R = RingSample{batch, n_envs, slots, reserve, reinterpret_cast<const long long *>(k_dev), obs, act, rew, done, seed, sb,
+    R = RingSample{batch, n_envs, slots, reserve, lag, reinterpret_cast<const long long *>(k_dev), obs, act, rew, done, seed, sb,
                    s_out, a_out, r_out, s2_out, d_out, idx_out};
     return TT_OK;
 }
@@ -345,7 +345,7 @@ int tt_actor_act_ring(int n, const tt_ring_view *ring, const tt_mlp_weights *w, 
                       const int64_t *step_dev, float theta_dt, float sigma_sqrt_dt, float high, float *act_scaled_out,
                       tt_stream_t stream) {
     if (n <= 0 || !ring || !ring->cursor || !ring->obs || !ring->act || !ring->done || ring->n_envs != n || !ou_state ||
-        !act_scaled_out || !check_ptrs(w, false) || !w->split_ws || !w->ws_packed)
+        !step_dev || !act_scaled_out || !check_ptrs(w, false) || !w->split_ws || !w->ws_packed)
         return TT_EINVAL;          // (ring addressing goes with a caller-kept image: the pack launch writes the cursor)
     ActArgs act{};
     act.ou = ou_state; act.done_prev = ring->done; act.act_raw = ring->act; act.act_scaled = act_scaled_out;
@@ -357,11 +357,12 @@ int tt_actor_act_ring(int n, const tt_ring_view *ring, const tt_mlp_weights *w, 
 }
 
 int tt_ring_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const float *obs, const float *act,
-                   const float *rew, const uint8_t *done, uint64_t seed, int reserve, const tt_side_buffer *side, float *s_out,
-                   float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out, tt_stream_t stream) {
+                   const float *rew, const uint8_t *done, uint64_t seed, int reserve, int lag, const tt_side_buffer *side,
+                   float *s_out, float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out,
+                   tt_stream_t stream) {
     RingSample R;
-    const int rc = make_sample(batch, n_envs, slots, k_dev, obs, act, rew, done, seed, reserve, side, s_out, a_out, r_out, s2_out,
-                               d_out, idx_out, R);
+    const int rc = make_sample(batch, n_envs, slots, k_dev, obs, act, rew, done, seed, reserve, lag, side, s_out, a_out, r_out,
+                               s2_out, d_out, idx_out, R);
     if (rc != TT_OK || batch == 0) return rc;
     hipLaunchKernelGGL(k_ring_sample, dim3(batch), dim3(64), 0, stream, R);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
@@ -372,7 +373,7 @@ int tt_mlp_split_pack_and_sample(const tt_mlp_weights *w, int critic, void *ws, 
     if (!ws || !a || !check_ptrs(w, critic != 0)) return TT_EINVAL;
     RingSample R;
     const int rc = make_sample(a->batch, a->n_envs, a->slots, a->k_dev, a->obs, a->act, a->rew, a->done, a->seed, a->reserve,
-                               a->side, a->s_out, a->a_out, a->r_out, a->s2_out, a->d_out, a->idx_out, R);
+                               a->lag, a->side, a->s_out, a->a_out, a->r_out, a->s2_out, a->d_out, a->idx_out, R);
     if (rc != TT_OK) return rc;
     return split_pack_and_sample(w, critic != 0, ws, R, to_cursor(cursor), stream);
 }

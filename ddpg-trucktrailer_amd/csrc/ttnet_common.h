@@ -29,14 +29,21 @@ struct ActArgs {                        // optional fused choose_action epilogue
     float decay, scale, high;           // 1 - theta*dt, sigma*sqrt(dt), action_space.high
     // Optional ring addressing (tt_actor_act_ring): obs / act_raw / done_prev are then the BASES of the trajectory ring's
     // obs [slots,n,23], act [slots,n], done [slots,n] and the slot comes from the device cursor {t, t+1, t-1, t > 0} that the
-    // step's opening pack launch wrote -- so one captured launch serves every ring position
-    const int *cursor;
+    // step's opening pack launch wrote -- so one captured launch serves every ring position.  The cursor buffer holds
+    // three of them: [4..7] written for even steps, [8..11] for odd steps (the opening launch of step t+1 may run beside the
+    // launches of step t), [0..3] the running step's copy that this launch leaves for the env step.  step_dev is then
+    // the ring's step counter: its parity picks the pair, and (tt_mlp_weights.split_ws_alt) the policy image.
+    int *cursor;
     int ring_n;
 };
 
+// the running step's cursor: the one of the parity of the ring's step counter
+__device__ __forceinline__ const int *cursor_of(const ActArgs &act) {
+    return act.cursor + 4 + 4 * (int)(*act.step_dev & 1);
+}
 // obs rows of this forward: the pointer itself, or slot cursor[0] of the ring
 __device__ __forceinline__ const float *resolve_obs(const ActArgs &act, const float *obs) {
-    return act.cursor ? obs + (size_t)act.cursor[0] * act.ring_n * IN : obs;
+    return act.cursor ? obs + (size_t)cursor_of(act)[0] * act.ring_n * IN : obs;
 }
 
 __device__ inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
@@ -70,8 +77,9 @@ __device__ __forceinline__ void finish_row(const int row, const float v, float *
         const uint8_t *done_prev = act.done_prev;
         float *act_raw = act.act_raw;
         if (act.cursor) {
-            done_prev = act.cursor[3] ? act.done_prev + (size_t)act.cursor[2] * act.ring_n : nullptr;
-            act_raw += (size_t)act.cursor[0] * act.ring_n;
+            const int *c = cursor_of(act);
+            done_prev = c[3] ? act.done_prev + (size_t)c[2] * act.ring_n : nullptr;
+            act_raw += (size_t)c[0] * act.ring_n;
         }
         if (done_prev && done_prev[row]) x = 0.f;
         const unsigned long long st = act.step + (act.step_dev ? (unsigned long long)*act.step_dev : 0ull);
@@ -104,7 +112,7 @@ struct SideBuf {
     int count;
 };
 struct RingSample {
-    int batch, n_envs, slots, reserve;
+    int batch, n_envs, slots, reserve, lag;
     const long long *k_dev;
     const float *obs, *act, *rew;
     const uint8_t *done;
@@ -117,7 +125,9 @@ struct RingSample {
 
 __device__ inline void ring_sample_row(const RingSample &R, const int b, const int lane) {
     const int n_envs = R.n_envs, slots = R.slots;
-    const long long k = *R.k_dev;                     // vector steps completed; transitions k-avail .. k-1 are intact
+    // vector steps completed; transitions k-avail .. k-1 are intact.  lag: that many of the newest steps may still be under
+    // way on another stream when this draw runs (a loop whose learn() chain runs ahead of its env steps)
+    const long long k0 = *R.k_dev - R.lag, k = k0 > 0 ? k0 : 0;
     const long long cap = slots - 1 - R.reserve;      // reserve: slots a concurrent env step is overwriting (pipelined loop)
     const long long avail = k < cap ? k : cap;
     uint32_t r[4];
@@ -166,10 +176,11 @@ struct RingCursor {
 __device__ __forceinline__ void write_cursor(const RingCursor &c) {
     if (!c.cursor) return;
     const long long k = *c.k_dev;
-    c.cursor[0] = (int)(k % c.slots);
-    c.cursor[1] = (int)((k + 1) % c.slots);
-    c.cursor[2] = (int)((k + c.slots - 1) % c.slots);
-    c.cursor[3] = k > 0 ? 1 : 0;
+    int *out = c.cursor + 4 + 4 * (int)(k & 1);      // the pair of this step's parity (ActArgs above)
+    out[0] = (int)(k % c.slots);
+    out[1] = (int)((k + 1) % c.slots);
+    out[2] = (int)((k + c.slots - 1) % c.slots);
+    out[3] = k > 0 ? 1 : 0;
 }
 
 // csrc/ttnet_split.hip

@@ -110,7 +110,11 @@ __device__ __forceinline__ f32x16 mfma_f16(const uint4 a, const uint4 b, const f
 //     carries the bias, the observation operand carries a 1 there);
 //   vec: g1*SX | be1*SX [2][416], b2 | g2 | be2 | w3 | wa | ba [6][320], zero beyond the real neurons; then b3.
 __device__ __forceinline__ void split_pack_body(const Weights &W, const bool critic, unsigned char *__restrict__ ws,
-                                                long long *__restrict__ bump, const RingCursor &cur, const int idx) {
+                                                unsigned char *__restrict__ ws_alt, long long *__restrict__ bump,
+                                                const RingCursor &cur, const int idx) {
+    // two images (tt_mlp_weights.split_ws_alt): the one of the parity of the step this launch opens, so that the launch may
+    // run beside a forward of the previous step that still reads the other
+    if (ws_alt && cur.k_dev && (*cur.k_dev & 1)) ws = ws_alt;
     if (idx == 0) {
         if (bump) *bump += 1;              // optional step counter of a pipelined loop (read by LATER launches only)
         write_cursor(cur);                 // ring slots of the step this launch opens (nothing advances k_dev right now)
@@ -166,17 +170,19 @@ constexpr int PACK_THREADS = (STEPS * T2 + S1 * T1) * 64 + VEC_BYTES / 4;
 constexpr int PACK_BLOCKS = (PACK_THREADS + 255) / 256;
 
 __global__ __launch_bounds__(256) void k_split_pack(const Weights W, const bool critic, unsigned char *__restrict__ ws,
-                                                    long long *__restrict__ bump, const RingCursor cur) {
-    split_pack_body(W, critic, ws, bump, cur, blockIdx.x * 256 + threadIdx.x);
+                                                    unsigned char *__restrict__ ws_alt, long long *__restrict__ bump,
+                                                    const RingCursor cur) {
+    split_pack_body(W, critic, ws, ws_alt, bump, cur, blockIdx.x * 256 + threadIdx.x);
 }
 
 // What opens a pipelined vector step, in ONE launch (two small kernels would each cost their ~4 us of launch and a
 // dependency gap on the loop's critical path): the policy's image from the actor's current weights, and the first batch of
 // this step's learn() from the replay ring (four sampled transitions per 256-thread workgroup).
 __global__ __launch_bounds__(256) void k_pack_and_sample(const Weights W, const bool critic, unsigned char *__restrict__ ws,
-                                                         const RingSample R, const RingCursor cur) {
+                                                         unsigned char *__restrict__ ws_alt, const RingSample R,
+                                                         const RingCursor cur) {
     if ((int)blockIdx.x < PACK_BLOCKS) {
-        split_pack_body(W, critic, ws, nullptr, cur, blockIdx.x * 256 + threadIdx.x);
+        split_pack_body(W, critic, ws, ws_alt, nullptr, cur, blockIdx.x * 256 + threadIdx.x);
         return;
     }
     const int b = ((int)blockIdx.x - PACK_BLOCKS) * 4 + (threadIdx.x >> 6);
@@ -186,7 +192,8 @@ __global__ __launch_bounds__(256) void k_pack_and_sample(const Weights W, const 
 template <bool CRITIC>
 __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int tile0, const float *__restrict__ obs,
                                                       const float *__restrict__ action,
-                                                      const unsigned char *__restrict__ ws, float *__restrict__ out,
+                                                      const unsigned char *__restrict__ ws,
+                                                      const unsigned char *__restrict__ ws_alt, float *__restrict__ out,
                                                       const ActArgs act) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint4 *ring = reinterpret_cast<const uint4 *>(lds_raw);             // RING x one k16 step of packed fc2
@@ -210,7 +217,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     // One 128-env tile per workgroup (a loop over tiles inside the kernel costs ~400 spilled registers: the compiler hoists
     // the tile-invariant DMA addresses); a caller that wants CUs left free launches the tiles in several grids (tile0).
     const int tile = tile0 + blockIdx.x;
-    const unsigned char *wsl = ws;
+    // ring addressing: the image of the running step's parity (the other one may be being written for the next step), and
+    // the first workgroup leaves the running step's cursor where the env step reads it
+    const bool odd = act.cursor && (*act.step_dev & 1);
+    const unsigned char *wsl = (odd && ws_alt) ? ws_alt : ws;
+    if (act.cursor && tile == 0 && tid < 4) act.cursor[tid] = cursor_of(act)[tid];
     const int row = tile * ROWS + wave * WROWS + r;                           // this lane's env (lanes r and r+32 share it)
 
     // LDS is filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = one 1 KB piece per wave-instruction, no
@@ -512,15 +523,18 @@ int split_debug_block_stamps(unsigned long long *out, int nblocks) {
 size_t split_ws_bytes() { return (size_t)WS_BYTES; }
 
 int split_pack(const tt_mlp_weights *w, bool critic, void *ws, long long *bump, const RingCursor &cur, hipStream_t stream) {
+    // (the second image takes part only when the caller packs into the struct's own workspace)
+    unsigned char *alt = ws == w->split_ws ? reinterpret_cast<unsigned char *>(w->split_ws_alt) : nullptr;
     hipLaunchKernelGGL(k_split_pack, dim3(PACK_BLOCKS), dim3(256), 0, stream, to_weights(w), critic,
-                       reinterpret_cast<unsigned char *>(ws), bump, cur);
+                       reinterpret_cast<unsigned char *>(ws), alt, bump, cur);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 
 int split_pack_and_sample(const tt_mlp_weights *w, bool critic, void *ws, const RingSample &R, const RingCursor &cur,
                           hipStream_t stream) {
+    unsigned char *alt = ws == w->split_ws ? reinterpret_cast<unsigned char *>(w->split_ws_alt) : nullptr;
     hipLaunchKernelGGL(k_pack_and_sample, dim3(PACK_BLOCKS + (R.batch + 3) / 4), dim3(256), 0, stream, to_weights(w), critic,
-                       reinterpret_cast<unsigned char *>(ws), R, cur);
+                       reinterpret_cast<unsigned char *>(ws), alt, R, cur);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 
@@ -550,11 +564,13 @@ static int launch_split(int n, const float *obs, const float *action, const tt_m
     for (int t0 = 0; t0 < capped; t0 += cap) {
         const int g = capped - t0 < cap ? capped - t0 : cap;
         hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(g), dim3(256), LDS_BYTES, stream, n, t0, obs, action,
-                           reinterpret_cast<const unsigned char *>(w->split_ws), out, act);
+                           reinterpret_cast<const unsigned char *>(w->split_ws),
+                           reinterpret_cast<const unsigned char *>(w->split_ws_alt), out, act);
     }
     if (capped < ntiles)
         hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(ntiles - capped), dim3(256), LDS_BYTES, stream, n, capped, obs, action,
-                           reinterpret_cast<const unsigned char *>(w->split_ws), out, act);
+                           reinterpret_cast<const unsigned char *>(w->split_ws),
+                           reinterpret_cast<const unsigned char *>(w->split_ws_alt), out, act);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 

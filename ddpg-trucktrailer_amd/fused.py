@@ -72,7 +72,7 @@ def weights_of(net):
     return w
 
 
-def packed_weights_of(net, index, max_workgroups=None, capped_grids=None):
+def packed_weights_of(net, index, max_workgroups=None, capped_grids=None, two_images=None):
     """TTMlpWeights whose split-kernel image is kept current BY THE CALLER (pack()): one of two private workspaces per
     module (index 0 / 1), so a loop can fill the image for the next step while a forward still reads this step's.
     Forwards through it never re-pack and read nothing of the live parameters."""
@@ -88,6 +88,11 @@ def packed_weights_of(net, index, max_workgroups=None, capped_grids=None):
         hit[1].max_workgroups = int(max_workgroups)
     if capped_grids is not None:
         hit[1].capped_grids = int(capped_grids)
+    if two_images and not hit[1].split_ws_alt:
+        # a second image for odd steps (ring addressing: include/ttenv.h, tt_mlp_weights.split_ws_alt), kept with the struct
+        alt = torch.empty(int(L.load().tt_mlp_split_ws_bytes()), dtype=torch.uint8, device=net.fc2.weight.device)
+        hit[1].split_ws_alt = alt.data_ptr()
+        cache[index] = hit + (alt,)
     return hit[1]
 
 

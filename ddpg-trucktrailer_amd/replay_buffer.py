@@ -73,7 +73,8 @@ class TrajectoryRing:
         self.side_epoch = 0
         # {t, t+1, t-1, t > 0}: ring slots of the running vector step, written on the device by the step's opening launch
         # (include/ttenv.h: tt_ring_view / tt_ring_cursor) so that captured launches need no per-position pointers
-        self.cursor_dev = torch.zeros(4, dtype=torch.int32, device=device)
+        # [4..7] / [8..11]: the cursors {t, t+1, t-1, t > 0} of even / odd steps, [0..3]: the running step's (include/ttenv.h)
+        self.cursor_dev = torch.zeros(12, dtype=torch.int32, device=device)
 
     def attach(self, env):
         """Let the env's step kernel advance k_dev (tt_env_set_step_counter): one launch less per vector step.  From
@@ -161,9 +162,12 @@ class TrajectoryRing:
         return L.TTRingView(self.cursor_dev.data_ptr(), self.obs.data_ptr(), self.act.data_ptr(), self.rew.data_ptr(),
                             self.done.data_ptr(), self.n, self.slots)
 
-    def cursor(self):
+    def cursor(self, counter=None):
+        """tt_ring_cursor for a step's opening launch; counter: the device step counter to take the step number from (default:
+        the ring's own; a loop whose opening launch may run before the previous env step has advanced that one passes its
+        own count of opened steps)."""
         from ddpg_trucktrailer_amd import _lib as L
-        return L.TTRingCursor(self.k_dev.data_ptr(), self.slots, 0, self.cursor_dev.data_ptr())
+        return L.TTRingCursor((self.k_dev if counter is None else counter).data_ptr(), self.slots, 0, self.cursor_dev.data_ptr())
 
     def _batch_bufs(self, batch_size):
         # one set per batch size, kept for the ring's lifetime: captured graphs hold these addresses, so a draw of another
@@ -178,7 +182,7 @@ class TrajectoryRing:
         self._bufs = cache[batch_size]          # (the set of the latest draw)
         return self._bufs
 
-    def sample_args(self, batch_size, seed=0, k_dev=None, reserve=0):
+    def sample_args(self, batch_size, seed=0, k_dev=None, reserve=0, lag=0):
         """tt_sample_args for one draw into the ring's batch buffers (include/ttenv.h); keeps what it points at alive."""
         from ddpg_trucktrailer_amd import _lib as L
         s, a, r, s2, dn, idx = self._batch_bufs(batch_size)
@@ -188,20 +192,21 @@ class TrajectoryRing:
         import ctypes as C
         return L.TTSampleArgs(batch_size, self.n, self.slots, int(reserve), p(self.k_dev if k_dev is None else k_dev),
                               p(self.obs), p(self.act), p(self.rew), p(self.done), int(seed) & (2 ** 64 - 1),
-                              C.pointer(side) if side is not None else None, p(s), p(a), p(r), p(s2), p(dn), p(idx))
+                              C.pointer(side) if side is not None else None, p(s), p(a), p(r), p(s2), p(dn), p(idx), int(lag), 0)
 
-    def sample_fused(self, batch_size, seed=0, return_index=False, done_as_bool=True, k_dev=None, reserve=0):
+    def sample_fused(self, batch_size, seed=0, return_index=False, done_as_bool=True, k_dev=None, reserve=0, lag=0):
         """sample() as ONE HIP launch (tt_ring_sample): Philox indices keyed by (seed, k_dev) + gather.
         done_as_bool=False returns the raw uint8 flags (no conversion launch; what the fused learner takes).
-        k_dev / reserve: another device step counter and the number of newest slots to keep out of the window (a pipelined
-        loop samples BESIDE the env step of the same vector step: include/ttenv.h, tt_ring_sample)."""
+        k_dev / reserve / lag: another device step counter, the number of newest slots to keep out of the window and the
+        number of counted steps that may still be under way (a pipelined loop samples BESIDE the env steps of the running
+        and of the previous vector step: include/ttenv.h, tt_ring_sample)."""
         import ctypes as C
         from ddpg_trucktrailer_amd import _lib as L
         s, a, r, s2, dn, idx = self._batch_bufs(batch_size)
         p = lambda t: C.c_void_p(t.data_ptr())
         side = self._side_struct()
         L.check(L.load().tt_ring_sample(batch_size, self.n, self.slots, p(self.k_dev if k_dev is None else k_dev), p(self.obs),
-                                        p(self.act), p(self.rew), p(self.done), int(seed) & (2 ** 64 - 1), int(reserve),
+                                        p(self.act), p(self.rew), p(self.done), int(seed) & (2 ** 64 - 1), int(reserve), int(lag),
                                         C.byref(side) if side is not None else None,
                                         p(s), p(a), p(r), p(s2), p(dn), p(idx),
                                         C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))

@@ -163,7 +163,8 @@ int tt_env_step(tt_env *env, const float *action, float *obs, float *reward, uin
  * tt_ring_cursor of tt_mlp_split_pack[_and_sample]).  Launches that take a view read / write the step's slots through the
  * cursor instead of through per-slot pointers, so ONE captured hipGraph serves every ring position. */
 typedef struct tt_ring_view {
-    const int32_t *cursor;  /* [4] device */
+    int32_t *cursor;        /* [12] device: [4..7] / [8..11] the cursors of even / odd steps (written by the opening launch of
+                               the step), [0..3] the running step's copy, left by tt_actor_act_ring for tt_env_step_ring */
     float *obs, *act, *rew;
     uint8_t *done;
     int32_t n_envs, slots;
@@ -171,7 +172,7 @@ typedef struct tt_ring_view {
 typedef struct tt_ring_cursor {
     const int64_t *k_dev;   /* vector steps completed (tt_env_set_step_counter); nothing may advance it beside the launch */
     int32_t slots, reserved_;
-    int32_t *cursor;        /* [4] device, written */
+    int32_t *cursor;        /* [12] device (tt_ring_view): the launch writes the four numbers of step *k_dev at [4 + 4 (k & 1)] */
 } tt_ring_cursor;
 /* tt_env_step with obs -> ring slot t+1, reward and done -> slot t (env.step of the vector loop, trainv2.py:520-525). */
 int tt_env_step_ring(tt_env *env, const float *action, const tt_ring_view *ring, int auto_reset, tt_stream_t stream);
@@ -229,6 +230,10 @@ typedef struct tt_mlp_weights {
                                re-pack and read nothing but the image, so the weights may be updated beside them */
     int32_t max_workgroups; /* > 0: the split kernel's workgroups (one per CU is resident) go out in consecutive grids of at most
                                this many, leaving the other CUs to launches on other streams; 0 = one grid */
+    void *split_ws_alt;     /* optional second image (ring addressing only): tt_mlp_split_pack[_and_sample] with a cursor then writes the
+                               image of the parity of the step it opens (split_ws: even steps, split_ws_alt: odd steps) and
+                               tt_actor_act_ring reads the one of the running step's parity -- so the opening launch of step
+                               t+1 may run beside the policy launches of step t */
     void *fc2_img;          /* learn() kernels (tt_mlp_forward_save / _multi, tt_mlp_backward*): NULL = fc2 products on the exact-f32
                                MFMA straight from w2; else a caller-owned device buffer of tt_mlp_fc2_image_bytes() bytes (zeroed
                                once, then tt_mlp_fc2_image_pack) that holds w2 as pre-split f16 pieces in both orientations, and
@@ -278,7 +283,9 @@ int tt_actor_act_ring(int n, const tt_ring_view *ring, const tt_mlp_weights *w, 
  * idx_out [batch,2] i32 (slot, env) or NULL.
  * reserve: 0, or the number of most recent ring slots a CONCURRENT env step may be writing (a pipelined loop samples
  * beside the step launch: then *k_dev counts the steps completed before that launch and reserve = 1 keeps the draw off the
- * observation row it overwrites); the window is min(*k_dev, slots - 1 - reserve) steps.
+ * observation row it overwrites); the window is min(*k_dev - lag, slots - 1 - reserve) steps ending lag steps before *k_dev
+ * (lag: steps counted by *k_dev that may still be under way on another stream -- a loop whose learn() chain runs ahead of its
+ * env steps: DDPGRollout's pipelined order uses lag = 1, reserve = 2).
  * side (may be NULL): stand-alone transitions that are not part of any env's trajectory -- the expert tuples
  * `(obs, action / radians(45), reward, obs_next, done)` that trainv2.py:457-466 re-inserts with agent.remember
  * (produced by exp_gen.py:77-110).  They take part in the same uniform draw: with `count` side transitions and R
@@ -290,14 +297,15 @@ typedef struct tt_side_buffer {
     int32_t count, reserved_;
 } tt_side_buffer;
 int tt_ring_sample(int batch, int n_envs, int slots, const int64_t *k_dev, const float *obs, const float *act,
-                   const float *rew, const uint8_t *done, uint64_t seed, int reserve, const tt_side_buffer *side, float *s_out,
-                   float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out, tt_stream_t stream);
+                   const float *rew, const uint8_t *done, uint64_t seed, int reserve, int lag, const tt_side_buffer *side,
+                   float *s_out, float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out,
+                   tt_stream_t stream);
 
 /* tt_mlp_split_pack + tt_ring_sample in ONE launch: what opens a vector step of a pipelined loop (the policy's image from
  * the actor's current weights; the first batch of the step's learn()).  The members of tt_sample_args are tt_ring_sample's
  * arguments. */
 typedef struct tt_sample_args {
-    int32_t batch, n_envs, slots, reserve;
+    int32_t batch, n_envs, slots, reserve;      /* (lag: last member) */
     const int64_t *k_dev;
     const float *obs, *act, *rew;
     const uint8_t *done;
@@ -306,6 +314,7 @@ typedef struct tt_sample_args {
     float *s_out, *a_out, *r_out, *s2_out;
     uint8_t *d_out;
     int32_t *idx_out;
+    int32_t lag, reserved_;  /* lag: the newest `lag` steps counted by *k_dev may still be under way (tt_ring_sample) */
 } tt_sample_args;
 int tt_mlp_split_pack_and_sample(const tt_mlp_weights *w, int critic, void *ws, const tt_sample_args *sample,
                                  const tt_ring_cursor *cursor, tt_stream_t stream);

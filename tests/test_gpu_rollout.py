@@ -374,10 +374,16 @@ def test_pipelined_and_serial_orders(gpu_device, pipeline):
     assert int(a.learner.step_dev.item()) == int(b.learner.step_dev.item()) == want
     if pipeline:
         assert int(a.k_pipe_dev.item()) == int(b.k_pipe_dev.item()) == k
-        # the window of the next batch: steps k-6 .. k-1 (slots - 2 = 6 of them), never the slot the env step is writing
-        _, _, _, _, _, idx = a.ring.sample_fused(4096, seed=1, return_index=True, k_dev=a.k_pipe_dev, reserve=1)
+        # the window of the next batch (step k): steps k-6 .. k-2 (slots - 3 = 5 of them) -- not step k-1, which may still be
+        # under way beside the draw, and never a slot the env steps k-1 and k are writing
+        from ddpg_trucktrailer_amd.rollout import _PIPE_LAG, _PIPE_RESERVE
+        assert (_PIPE_LAG, _PIPE_RESERVE) == (1, 2)
+        _, _, _, _, _, idx = a.ring.sample_fused(4096, seed=1, return_index=True, k_dev=a.k_pipe_dev, reserve=_PIPE_RESERVE,
+                                                 lag=_PIPE_LAG)
         t = idx[:, 0].long()
-        assert set(t.unique().tolist()) == {(k - 1 - j) % 8 for j in range(6)}
+        assert set(t.unique().tolist()) == {(k - 2 - j) % 8 for j in range(5)}
+        writing = {(k - 1 + 1) % 8, (k + 1) % 8}                   # obs rows of the env steps k-1 and k
+        assert not (set(t.tolist()) | set(((t + 1) % 8).tolist())) & writing
         # the policy acted with an image of the actor as learn() of the previous step left it: run one more step and compare
         # the stored action means with the pre-step actor on the observations the policy saw
         obs = a.ring.obs[a.ring.slot()].clone()
