@@ -326,8 +326,8 @@ def main():
                       "three hipGraph segments per step with the two RCCL gradient all-reduces between them")
         else:
             launch = "eager, learn() as a hipGraph" if loop.use_graph else "eager"
-        order = ("pipelined: learn() of vector step t (batch from the steps before t) runs beside the policy + env launches of "
-                 "step t on a second graph branch; the policy acts with the weights learn() of step t-1 left"
+        order = ("pipelined: learn() of vector step t (batch from the steps up to t-2) runs beside the policy + env launches of "
+                 "steps t-1 and t on a second chain of the graph; the policy acts with the weights learn() of step t-1 left"
                  if loop.pipeline else "serial: policy, env step, then learn() on a window that includes the new step")
         extra = {"batch": args.batch, "updates_per_step": args.updates_per_step,
                  "replay_capacity": args.replay_slots * n, "launch": launch, "order": order,

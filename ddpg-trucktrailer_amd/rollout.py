@@ -8,23 +8,27 @@ Per vector step, for all N envs of this rank at once:
                                                    obs', r, done are written by the kernel straight into the ring
     learn() x updates_per_step                     (gradient steps, each on a fresh batch from the ring)
 Everything stays on the device.  run(k) replays hipGraphs of whole vector steps (policy, env step and learn(): seven to
-nine launches per step with no host in between): ONE graph of `graph_steps` steps and ONE single-step graph serve every
+nine launches per step with no host in between): graphs of `graph_steps`, 4 and 1 steps serve every
 ring position (the launches find the step's ring slots through a device cursor), so that no step of a run() is launched
 eagerly whatever k and the position are.  step() is the same vector step launched eagerly.  All of them give the same bits.
 
-Data-parallel ranks (one process per GPU): a step is three graph segments with the two gradient all-reduces of
-DDPG_agent.py:95-104 between them, launched eagerly on RCCL (the collectives are not captured).
+Data-parallel ranks (one process per GPU): the two gradient all-reduces of DDPG_agent.py:95-104 are nodes of the step's
+graph when dp_probe found captured RCCL collectives working on this node; else a step is three graph segments with
+eager collectives between them.
 
 pipeline=True (the default on a GPU with the fused learner): learn() of vector step t runs BESIDE the policy and env
-launches of step t, on a second stream / graph branch, and the two meet at the end of the step.  What this needs:
-  * learn() of step t samples transitions of steps < t (the reference's, and pipeline=False's, window also holds step t:
-    a one-slot difference, stated like the other choices of the vector loop);
-  * the policy reads a packed IMAGE of the actor (csrc/ttnet_split.hip) made at the start of step t, before the two
-    branches part, from the weights learn() of step t-1 left -- never the live weights learn() of step t is updating -- so
-    the policy of step t acts with the weights after learn() of step t-1, exactly as in the serial order;
+launches of steps t-1 and t, on a second stream.  What this needs:
+  * learn() of step t draws from the steps up to t-2 (_PIPE_LAG / _PIPE_RESERVE below; the reference's, and
+    pipeline=False's, window also holds steps t-1 and t: a two-slot difference, stated like the other choices of the
+    vector loop);
+  * the policy reads a packed IMAGE of the actor (csrc/ttnet_split.hip) made by the opening launch of step t from the
+    weights learn() of step t-1 left -- never the live weights learn() of step t is updating -- so the policy of step t
+    acts with the weights after learn() of step t-1, exactly as in the serial order; image and ring cursor exist twice
+    (even / odd steps), because the opening launch of step t may run beside the policy of step t-1;
   * the policy kernel's grid is capped (policy_workgroups) so that learn()'s launches always find free CUs.
-No launch of one branch reads what a launch of the other writes within a step, so graphs, eager launches and a resumed
-run still agree bit for bit."""
+Captured graphs hold the two chains with one edge each way per step (_capture_lagged); eager steps join the two streams at
+the end of every step, which is stricter; no launch reads what a concurrent one writes, so graphs, eager launches and a
+resumed run still agree bit for bit."""
 import math
 import os
 
