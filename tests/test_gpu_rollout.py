@@ -398,3 +398,32 @@ def test_pipelined_and_serial_orders(gpu_device, pipeline):
         assert not torch.equal(fused.actor_forward(a.agent.actor, obs).view(-1), mu_before)   # learn() did move the actor meanwhile
     for lp in loops:
         lp.env.close()
+
+
+@pytest.mark.parametrize("n", [1000, 77])
+def test_ragged_env_counts_graphs_match_eager(gpu_device, n):
+    """N that is no multiple of the 64-env tiles of the step kernel nor of the 128-env tiles of the policy kernel (and, for 77,
+    below one tile): the graphs of the pipelined loop (two chains, ring cursor, two policy images) == eager steps, bit for
+    bit, over a run that wraps the ring twice; nothing outside the N envs is touched (guard rows stay as they were)."""
+    import torch
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    loops = []
+    for graph_steps in (20, 0):
+        env = TruckTrailerVecEnv(n)
+        env.reset(seed=13)
+        loops.append(DDPGRollout(env, batch_size=64, replay_slots=8, seed=13, graph_steps=graph_steps))
+    a, b = loops
+    assert a.pipeline and b.pipeline
+    a.run(4 + 20 + 4 + 1 + 1)
+    for _ in range(30):
+        b.step()
+    torch.cuda.synchronize()
+    assert a.graphG is not None and a.graphM is not None and b.graph1 is None
+    assert torch.equal(_loop_flat(a), _loop_flat(b))
+    for name in ("obs", "act", "rew", "done"):
+        assert torch.equal(getattr(a.ring, name), getattr(b.ring, name)), name
+    assert torch.equal(a.noise.x, b.noise.x) and torch.equal(a.env.state, b.env.state)
+    assert torch.isfinite(_loop_flat(a)).all() and a.ring.obs.shape[1] == n
+    for lp in loops:
+        lp.env.close()
