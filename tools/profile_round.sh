@@ -19,7 +19,7 @@ python3 bench.py --n-envs 4096 --workload env --no-cpu-baseline > $out/bench_n40
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ddpg -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --repeats 0 > $out/ddpg.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ddpg_serial -- python3 bench.py --serial --steps 100 --warmup 20 --no-cpu-baseline --repeats 0 > $out/ddpg_serial.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/env -- python3 bench.py --workload env --steps 200 --no-cpu-baseline --repeats 0 > $out/env.log 2>&1 || exit 1
-python3 tools/timeline.py $out/ddpg 60 > $out/ddpg_step_timeline.txt 2>&1
+python3 tools/timeline.py $out/ddpg 71 > $out/ddpg_step_timeline.txt 2>&1
 python3 tools/timeline.py $out/ddpg_serial 60 > $out/ddpg_serial_step_timeline.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -- python3 bench.py --workload env --graph-steps 1 --steps 100 --warmup 20 --no-cpu-baseline --repeats 0 > $out/pmc_$c.log 2>&1 || exit 1
