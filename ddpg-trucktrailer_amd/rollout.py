@@ -112,7 +112,7 @@ class DDPGRollout:
         self.graph = None
         self._learn_side, self._learn_warm = None, 0
         # pipelined order (module docstring): needs the fused learner and the fused policy kernel
-        can_pipe = self.learner is not None and self.fused_act and self.device.type == "cuda" and replay_slots >= 4 \
+        can_pipe = self.learner is not None and self.fused_act and self.device.type == "cuda" and replay_slots >= 3 + _PIPE_RESERVE \
             and self.ring._env_counts
         self.pipeline = can_pipe if pipeline is None else (bool(pipeline) and can_pipe)
         self.policy_workgroups = int(os.environ.get("TT_POLICY_WG", policy_workgroups))     # (env: A/B measurements)

@@ -427,3 +427,26 @@ def test_ragged_env_counts_graphs_match_eager(gpu_device, n):
     assert torch.isfinite(_loop_flat(a)).all() and a.ring.obs.shape[1] == n
     for lp in loops:
         lp.env.close()
+
+
+def test_smallest_rings(gpu_device):
+    """The pipelined order needs a ring of 3 + reserve = 5 slots (window: 2 steps); with 4 the loop keeps the serial order."""
+    import torch
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    for slots, piped in ((5, True), (4, False)):
+        loops = []
+        for graph_steps in (4, 0):
+            env = TruckTrailerVecEnv(300)
+            env.reset(seed=3)
+            loops.append(DDPGRollout(env, batch_size=32, replay_slots=slots, seed=3, graph_steps=graph_steps))
+        a, b = loops
+        assert a.pipeline == b.pipeline == piped
+        a.run(17)
+        for _ in range(17):
+            b.step()
+        torch.cuda.synchronize()
+        assert torch.equal(_loop_flat(a), _loop_flat(b)) and torch.isfinite(_loop_flat(a)).all()
+        assert int(a.learner.step_dev.item()) == int(b.learner.step_dev.item()) == (15 if piped else 16)
+        for lp in loops:
+            lp.env.close()
