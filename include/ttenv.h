@@ -271,7 +271,9 @@ int tt_actor_act(int n, const float *obs, const tt_mlp_weights *w, float *ou_sta
                  float *mu_out, float *act_raw_out, float *act_scaled_out, tt_stream_t stream);
 
 /* tt_actor_act on ring slot t (observations in, stored actions out, done flags of slot t-1 restart the noise): `w` must carry a
- * caller-kept image (ws_packed). */
+ * caller-kept image (ws_packed).  step_dev (required) is the ring's step counter -- the one tt_env_step_ring's launch
+ * advances: besides keying the noise, its parity picks the cursor pair and (split_ws_alt) the image of the running step, and
+ * the launch copies that cursor to cursor[0..3] for the env step that follows it on the same stream. */
 int tt_actor_act_ring(int n, const tt_ring_view *ring, const tt_mlp_weights *w, float *ou_state, uint64_t seed, uint64_t step,
                       const int64_t *step_dev, float theta_dt, float sigma_sqrt_dt, float high, float *act_scaled_out,
                       tt_stream_t stream);
