@@ -256,12 +256,11 @@ class DDPGRollout:
         self.env.step(scaled, auto_reset=True, obs_out=ring.obs[t1], reward_out=ring.rew[t], done_out=ring.done[t])
 
     def _pipelined(self, k, learn, dp_capture=False):
-        """The running vector step (number k) in the pipelined order, on the current stream and the side stream:
-            current:  pack the policy's image from the actor as learn() of step k-1 left it; then, beside each other,
+        """The running vector step (number k) in the pipelined order with a JOIN at its end -- the eager form of a step, and
+        the first of the three graph segments of the data-parallel fallback (captured graphs of whole steps use
+        _capture_lagged: the same launches without the per-step join):
+            current:  opening launch (image + cursor + batch); then, beside each other,
             side:     learn(), whose last update moves the sampling window on      | current:  policy, env step
-        joined at the end.  The same code runs under capture (two branches of one graph) and eagerly (two streams).  The
-        pack sits BEFORE the fork: with it on the policy branch and an event into the middle of learn() (which would take
-        it off learn()'s path) ROCm's graph executor runs the two branches one after the other (tools/graph_probe2.py).
         dp_capture: only learn()'s first segment (up to the critic's gradient) goes beside the policy; _dp_step does the rest."""
         cur, side = torch.cuda.current_stream(self.device), self._pipe_side
         self._open_step(learn)     # image + cursor + (one kernel and one gap less) the first batch of this step's learn()

@@ -285,7 +285,7 @@ int tt_actor_act_ring(int n, const tt_ring_view *ring, const tt_mlp_weights *w, 
  * idx_out [batch,2] i32 (slot, env) or NULL.
  * reserve: 0, or the number of most recent ring slots a CONCURRENT env step may be writing (a pipelined loop samples
  * beside the step launch: then *k_dev counts the steps completed before that launch and reserve = 1 keeps the draw off the
- * observation row it overwrites); the window is min(*k_dev - lag, slots - 1 - reserve) steps ending lag steps before *k_dev
+ * observation row it overwrites; two env steps may be under way beside a draw that runs ahead of them: reserve = 2); the window is min(*k_dev - lag, slots - 1 - reserve) steps ending lag steps before *k_dev
  * (lag: steps counted by *k_dev that may still be under way on another stream -- a loop whose learn() chain runs ahead of its
  * env steps: DDPGRollout's pipelined order uses lag = 1, reserve = 2).
  * side (may be NULL): stand-alone transitions that are not part of any env's trajectory -- the expert tuples
