@@ -22,6 +22,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,7 +31,9 @@ if ROOT not in sys.path:
 
 B_ALG = 313            # algorithmic bytes per env-step
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+# the two gradient all-reduce sites of a data-parallel learn() (DDPG_agent.py:95-104): flat f32 buffers of these sizes
+GRAD_NUMEL = {"critic": 132201, "actor": 131601}
 
 
 def parse():
@@ -54,7 +57,88 @@ def parse():
     ap.add_argument("--serial", action="store_true", help="ddpg workload: the reference's strict order (policy, env step, then "
                     "learn() on a window that includes the new step) instead of the pipelined one")
     ap.add_argument("--graph-steps", type=int, default=50, help="env workload: vector steps per captured hipGraph")
+    ap.add_argument("--dp-mode", choices=("auto", "graph", "segments"), default="auto",
+                    help="N > 1, ddpg workload: launch structure of a data-parallel vector step.  graph: one hipGraph per step "
+                    "with the two RCCL all-reduces as its nodes; segments: three hipGraph segments with eager all-reduces "
+                    "between them; auto: graph where every rank's probe (dp_probe) saw a captured all-reduce replay "
+                    "correctly, else segments.  The structure that ran is in config.launch / config.dp_mode")
+    ap.add_argument("--watchdog-seconds", type=float, default=float(os.environ.get("TT_BENCH_WATCHDOG_S", "300")),
+                    help="N > 1: a phase of the run (set-up, warm-up, timed region, ...) that has not completed this many "
+                    "seconds after it began ends the rank with exit code 3 and a line that names rank and phase")
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------ N > 1 watchdog
+class Watchdog:
+    """A data-parallel run must not hang silently (a captured collective that the library mishandles stalls, it does not
+    raise).  A daemon thread per rank: when the running phase is older than its limit it writes ONE line -- rank, phase,
+    seconds -- to stderr and ends the process with os._exit(3) (no re-exec, no clean-up that could block on the GPU).
+    TT_BENCH_STALL="rank:phase" makes that rank sleep in that phase (the test of this class)."""
+
+    def __init__(self, rank, world, limit, out=None, period=0.25):
+        self.rank, self.world, self.limit = rank, world, float(limit)
+        self.out = out if out is not None else sys.stderr
+        self.phase, self.since, self.limits = "start", time.monotonic(), {}
+        self._stop = threading.Event()
+        self._period = period
+        self._thread = threading.Thread(target=self._watch, name="bench-watchdog", daemon=True)
+        self._thread.start()
+
+    def enter(self, phase, limit=None):
+        if limit is not None:
+            self.limits[phase] = float(limit)
+        self.phase, self.since = phase, time.monotonic()
+        stall = os.environ.get("TT_BENCH_STALL", "")
+        if stall == f"{self.rank}:{phase}":
+            while True:
+                time.sleep(3600)
+
+    def stop(self):
+        self._stop.set()
+
+    def _watch(self):
+        while not self._stop.wait(self._period):
+            phase, since = self.phase, self.since
+            age = time.monotonic() - since
+            if age > self.limits.get(phase, self.limit):
+                print(f"bench.py watchdog: rank {self.rank} of {self.world} has been in phase '{phase}' for {age:.0f} s "
+                      f"(limit {self.limits.get(phase, self.limit):.0f} s); giving up with exit code 3", file=self.out, flush=True)
+                os._exit(3)
+
+
+class _NoWatchdog:
+    def enter(self, phase, limit=None):
+        pass
+
+    def stop(self):
+        pass
+
+
+def allreduce_us(dev, world, reps=50):
+    """Wire + launch time of the two gradient all-reduces alone: `reps` eager AVG all-reduces of each site's flat f32 buffer,
+    event-timed back to back after 5 untimed ones; max over ranks.  Lets a scaling curve be split into time on the wire and
+    time on the chain (efficiency ~ t_1 / (t_1 + structure + 2 t_allreduce))."""
+    import torch
+    import torch.distributed as dist
+    out = {}
+    avg = dist.get_backend() == "nccl"
+    for site, numel in GRAD_NUMEL.items():
+        buf = torch.zeros(numel, dtype=torch.float32, device=dev)
+        one = (lambda: dist.all_reduce(buf, op=dist.ReduceOp.AVG)) if avg else (lambda: dist.all_reduce(buf))
+        for _ in range(5):
+            one()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            one()
+        b.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([a.elapsed_time(b) * 1e3 / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out[f"{site}_{numel * 4 // 1000}KB"] = float(t.item())
+    out["note"] = f"{reps} eager all-reduces per site back to back on backend {dist.get_backend()}, max over the {world} ranks"
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ N > 1 launcher
@@ -236,17 +320,29 @@ def main():
     if world != args.gpus:
         args.gpus = world                      # the line reports the ranks that actually run
 
+    wd = Watchdog(rank, world, args.watchdog_seconds) if world > 1 else _NoWatchdog()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_seconds)   # before any GPU call: its worker processes start from a GPU-free parent
 
-    if world > 1 and args.workload == "ddpg" and os.environ.get("TT_DIST_BACKEND", "nccl") == "nccl" \
-            and "TT_DP_GRAPH_COLLECTIVES" not in os.environ:
+    nccl = os.environ.get("TT_DIST_BACKEND", "nccl") == "nccl"
+    dp_vote, dp_asked = False, "n/a"
+    if world > 1 and args.workload == "ddpg" and nccl:
         # one hipGraph per data-parallel step if this node replays a captured RCCL all-reduce correctly: asked in
-        # throw-away child processes before this rank touches its GPU (ddpg-trucktrailer_amd/dp_probe.py)
-        from ddpg_trucktrailer_amd.dp_probe import graph_collectives_ok
-        os.environ["TT_DP_GRAPH_COLLECTIVES"] = "1" if graph_collectives_ok() else "0"
+        # throw-away child processes before this rank touches its GPU (ddpg-trucktrailer_amd/dp_probe.py).  The answer
+        # here is this rank's VOTE; the ranks agree on one structure below, once the process group exists.
+        if args.dp_mode == "auto" and "TT_DP_GRAPH_COLLECTIVES" in os.environ:
+            dp_vote, dp_asked = os.environ["TT_DP_GRAPH_COLLECTIVES"] == "1", "TT_DP_GRAPH_COLLECTIVES"
+        elif args.dp_mode == "auto":
+            from ddpg_trucktrailer_amd.dp_probe import graph_collectives_ok, probe_port
+            limit = min(240.0, max(30.0, args.watchdog_seconds - 60.0))
+            wd.enter("dp-probe", limit + 60.0)
+            dp_vote, dp_asked = graph_collectives_ok(timeout=limit, port=probe_port()), "probe"
+        else:
+            dp_vote, dp_asked = args.dp_mode == "graph", "--dp-mode " + args.dp_mode
 
+    wd.enter("init")
     import torch
     import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path is a HIP kernel)"
@@ -265,6 +361,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        from ddpg_trucktrailer_amd.dp_probe import agree
+        dp_graph = agree(dp_vote, dev)         # every rank builds the same launch structure
+    else:
+        dp_graph = False
 
     from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
 
@@ -312,9 +412,12 @@ def main():
         loop = DDPGRollout(env, batch_size=args.batch, replay_slots=args.replay_slots, seed=27 + rank,
                            world_size=world, use_graph=not args.no_graph, fused_learn=not args.torch_learn,
                            graph_steps=args.step_graph, updates_per_step=args.updates_per_step,
-                           pipeline=False if args.serial else None)
+                           pipeline=False if args.serial else None, graph_collectives=dp_graph)
+        wd.enter("prepare (eager steps + graph capture)")
         loop.prepare()       # one-off work (4 untimed vector steps + graph capture) before warm-up and the timed region
+        wd.enter("first graph launches")
         loop.first_launches()   # ... and the first launch of every captured graph (it uploads the graph)
+        torch.cuda.synchronize()
         ddpg_loop = loop
         run = loop.run       # every step a hipGraph replay (G-step graphs where aligned, single-step graphs elsewhere)
         workload = (f"{vname} N={n}/GPU + full DDPG learn() x{args.updates_per_step} per vector step (actor/critic 400x300, "
@@ -331,6 +434,9 @@ def main():
                  if loop.pipeline else "serial: policy, env step, then learn() on a window that includes the new step")
         extra = {"batch": args.batch, "updates_per_step": args.updates_per_step,
                  "replay_capacity": args.replay_slots * n, "launch": launch, "order": order,
+                 "dp_mode": (None if not loop.dp else
+                             {"asked": args.dp_mode, "decided_by": dp_asked, "this_rank_vote": bool(dp_vote),
+                              "agreed_by_all_ranks": "graph" if loop.dp_single_graph else "segments"}),
                  "env_steps_per_update": n / args.updates_per_step, "setup_vector_steps": loop.vector_steps,
                  "note": ("throughput of the configuration BASELINE.json names; how the same loop trains at this and at other "
                           "update ratios (--updates-per-step): profiles/r02_training_behaviour.md")}
@@ -341,8 +447,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    ar_us = None
+    if world > 1:
+        wd.enter("all-reduce timing")
+        ar_us = allreduce_us(dev, world)
+    wd.enter("warm-up")
     run(args.warmup)
     sync_all()
+    wd.enter("timed region")
     captured = graph_k > 1 or (ddpg_loop is not None and ddpg_loop.graph_steps > 0)
     if not captured:
         env.profile(args.steps)      # per-dispatch HIP events on the step kernel, inside the timed region
@@ -355,6 +467,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     event_ms = e0.elapsed_time(e1)
+    wd.enter("after the timed region (repeats, per-dispatch kernel timing)")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -431,12 +544,16 @@ def main():
             "algorithmic_f32_tflops": useful / (act_ms * 1e-3) / 1e12,
             "algorithmic_frac_of_16bit_peak": useful / (act_ms * 1e-3) / 1e12 / 2500.0,
             "f32_mfma_peak_tflops": 157.3}
+    if ar_us is not None:
+        out["allreduce_us"] = ar_us
     if rank == 0:
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
+    wd.enter("shutdown")
     if world > 1:
         dist.destroy_process_group()
+    wd.stop()
 
 
 if __name__ == "__main__":

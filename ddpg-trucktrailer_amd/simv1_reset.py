@@ -101,10 +101,17 @@ def plan_dubins_path_backward(sx, sy, syaw, gx, gy, gyaw, curvature, step_size=0
     return x, y, yaw - math.pi
 
 
+def points_out_of_map(px, py, lo=-40.0, hi=40.0):
+    """The in-map test of simv1.py:249-253 (== check_out_of_Map, :225-237, per point): a point ON an edge is inside.
+    Pinned to the reference by fixture F6 (path/*, oom/*)."""
+    px, py = np.asarray(px, dtype=np.float64), np.asarray(py, dtype=np.float64)
+    return bool(((px < lo) | (px > hi) | (py < lo) | (py > hi)).any())
+
+
 def path_out_of_map(sx, sy, syaw, gx, gy, gyaw, lo=-40.0, hi=40.0, curvature=1.0 / 6):
     """simv1.py:239-253."""
     px, py, _ = plan_dubins_path_backward(sx, sy, syaw, gx, gy, gyaw, curvature)
-    return bool(((px < lo) | (px > hi) | (py < lo) | (py > hi)).any())
+    return points_out_of_map(px, py, lo, hi)
 
 
 def generate_valid_random_pose(rng=random, goal=(0.0, -30.0, math.pi / 2), lo=-40.0, hi=40.0, max_attempts=1000):

@@ -109,6 +109,16 @@ class COracle:
         return obs, rew, done.astype(bool), info
 
 
+def rhs(y, steering, variant=0, L2=None):
+    """The ODE right-hand side of the restatement for one state (fixture F6 pins it to the reference's kinematic_model)."""
+    p = Params()
+    lib().tto_params_default(C.byref(p), variant)
+    y = np.ascontiguousarray(y, np.float64)
+    d = np.zeros(6, np.float64)
+    lib().tto_rhs(C.byref(p), C.c_double(p.L2 if L2 is None else L2), C.c_double(steering), _p(y, C.c_double), _p(d, C.c_double))
+    return d
+
+
 def rollout_random(n_envs, n_steps, seed=0, nthreads=1, variant=0):
     p = Params()
     lib().tto_params_default(C.byref(p), variant)

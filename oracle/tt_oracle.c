@@ -126,6 +126,10 @@ static void rhs(const tto_params *p, double L2, double steering, const double *y
     d[5] = v2 * sin(y[1]);
 }
 
+/* the ODE right-hand side alone (simv2.py:269-303 == simv1.py:180-214): checked against the reference's kinematic_model
+ * by fixture F6 */
+void tto_rhs(const tto_params *p, double L2, double steering, const double y[6], double d[6]) { rhs(p, L2, steering, y, d); }
+
 static void integrate(const tto_params *p, double L2, double steering, double *y) {
     static const double A[6][5] = {{0},
                                    {1.0 / 5},

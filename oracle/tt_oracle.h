@@ -50,6 +50,7 @@ int tto_env_size(void);
 void tto_params_default(tto_params *p, int variant);
 void tto_place(const tto_params *p, tto_env *e, const double start[3], const double goal[3], double L2, float *obs);
 void tto_set_state(tto_env *e, const double y[6]);
+void tto_rhs(const tto_params *p, double L2, double steering, const double y[6], double d[6]);
 void tto_observe(const tto_params *p, const tto_env *e, double steering, float *obs);
 void tto_step(const tto_params *p, tto_env *e, float action, float *obs, double *reward, uint8_t *done, double *info);
 void tto_step_batch(const tto_params *p, tto_env *envs, int n, const float *actions, float *obs, double *reward,

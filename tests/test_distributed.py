@@ -179,18 +179,24 @@ def _nccl_loop_worker(rank, world, port, out_dir):
         variants.append(dict(graph_steps=4, data_parallel=True, graph_collectives=True))
     if world == 1:
         variants.append(dict(graph_steps=4, data_parallel=False))
+    steps = 13
+    if os.environ.get("TT_TEST_G20") == "1":
+        # the shape bench.py replays: ONE graph of 20 vector steps with 40 captured all-reduces in it, against eager steps
+        variants = [dict(graph_steps=20, data_parallel=True, graph_collectives=True), dict(graph_steps=0, data_parallel=True)]
+        steps = 4 + 20 + 4 + 1 + 20          # eager warm-up, then graphs of 20, 4, 1 and 20 again
     for kw in variants:
         env = TruckTrailerVecEnv(1024, device=dev)
         env.reset(seed=27 + rank)
         loop = DDPGRollout(env, batch_size=128, replay_slots=8, seed=27 + rank, world_size=world, **kw)
         assert loop.dp == kw["data_parallel"]
-        loop.run(13)
+        loop.run(steps)
         torch.cuda.synchronize()
         if kw["graph_steps"]:
             single = bool(kw.get("graph_collectives"))
             assert loop.dp_single_graph == single
             assert loop.graph1 is not None and (loop.dp_graphs is not None) == (loop.dp and not single)
             assert (loop.graphG is not None) == (single or not loop.dp)
+            assert (loop.graphM is not None) == (kw["graph_steps"] > 4 and (single or not loop.dp))
         flats.append(torch.cat([p.detach().reshape(-1) for net in loop.agent._nets() for p in net.parameters()]).cpu())
         env.close()
     torch.save(flats, os.path.join(out_dir, f"nccl{rank}.pt"))
@@ -214,6 +220,22 @@ def test_rccl_world_size_1_loop_graphs_match_eager(tmp_path, gpu_device):
     assert torch.equal(a[0], a[1]), "graph path differs from the eager path under RCCL"
     assert torch.equal(a[0], a[2]), "one graph per step with the all-reduces captured in it differs from the eager path"
     assert torch.equal(a[0], a[3]), "data-parallel structure at world size 1 differs from the single-rank loop"
+
+
+@pytest.mark.gpu
+def test_rccl_world_size_1_single_graph_of_20_steps(tmp_path, gpu_device):
+    """The data-parallel launch structure bench.py uses where the probe says yes -- one hipGraph of 20 whole vector steps,
+    the two gradient all-reduces of every step captured in it (40 RCCL nodes) -- on RCCL at world size 1: 49 steps through the
+    graphs of 20, 4 and 1 == 49 eager steps, bit for bit."""
+    port = _free_port()
+    os.environ["TT_TEST_G20"] = "1"
+    try:
+        mp.start_processes(_nccl_loop_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True, start_method="spawn")
+    finally:
+        os.environ.pop("TT_TEST_G20", None)
+    a = torch.load(tmp_path / "nccl0.pt", weights_only=True)
+    assert torch.isfinite(a[0]).all()
+    assert torch.equal(a[0], a[1]), "20-step graphs with captured all-reduces differ from eager data-parallel steps"
 
 
 @pytest.mark.gpu
@@ -291,3 +313,75 @@ def test_graph_collective_probe_says_no_without_a_working_child(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.delenv("TT_DP_PROBE_FORCE", raising=False)
     assert graph_collectives_ok(timeout=20.0) is False          # one rank: nothing to ask
+
+
+_WATCHDOG_RANK = r"""
+import os, sys, time
+sys.path.insert(0, %r)
+import bench
+import torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+wd = bench.Watchdog(rank, world, limit=4.0)
+wd.enter("init")
+dist.init_process_group("gloo", rank=rank, world_size=world)
+wd.enter("warm-up")          # TT_BENCH_STALL="1:warm-up": rank 1 never leaves this phase
+dist.barrier()               # ... and rank 0 waits here for it
+wd.enter("timed region")
+dist.barrier()
+wd.stop()
+print("finished", rank, flush=True)
+"""
+
+
+@pytest.mark.parametrize("stall", ["1:warm-up", ""])
+def test_bench_watchdog_names_the_stalled_rank_and_phase(stall):
+    """bench.py's watchdog for world > 1 (two gloo ranks on the CPU): a rank that stalls in a phase ends with exit code 3 and a
+    line that names rank and phase; the rank that waits for it in a collective ends the same way instead of hanging; with no
+    stall both ranks finish and the watchdog stays silent."""
+    import subprocess
+    import time
+    port = _free_port()
+    procs = []
+    t0 = time.monotonic()
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TT_BENCH_STALL=stall)
+        procs.append(subprocess.Popen([sys.executable, "-c", _WATCHDOG_RANK % ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    took = time.monotonic() - t0
+    if not stall:
+        assert [p.returncode for p in procs] == [0, 0], outs
+        assert all("watchdog" not in e for _, e in outs)
+        return
+    assert [p.returncode for p in procs] == [3, 3], outs
+    assert "watchdog: rank 1 of 2 has been in phase 'warm-up'" in outs[1][1]
+    assert "watchdog: rank 0 of 2 has been in phase 'warm-up'" in outs[0][1]      # blocked in the barrier behind rank 1
+    assert all("finished" not in o for o, _ in outs)
+    assert took < 60
+
+
+def test_probe_port_is_agreed_through_the_launcher_store():
+    """dp_probe.probe_port(): under torch.distributed.run every rank reads the port rank 0 found free from the agent's store
+    (no GPU, no process group needed); the ranks' votes are reduced with MIN by dp_probe.agree()."""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from ddpg_trucktrailer_amd import dp_probe\n"
+            "import torch.distributed as dist\n"
+            "p = dp_probe.probe_port()\n"
+            "dist.init_process_group('gloo')\n"
+            "r = dist.get_rank()\n"
+            "print('port', p, 'agree', dp_probe.agree(r == 0), dp_probe.agree(True), flush=True)\n"
+            "dist.destroy_process_group()\n" % ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "w.py")
+        with open(path, "w") as f:
+            f.write(code)
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                            "127.0.0.1", "--master-port", str(_free_port()), path], env=env, capture_output=True, text=True,
+                           timeout=240)
+    lines = [l.split() for l in r.stdout.splitlines() if l.startswith("port")]
+    assert r.returncode == 0 and len(lines) == 2, r.stdout + r.stderr
+    assert lines[0][1] == lines[1][1] and int(lines[0][1]) > 0          # one port for both ranks
+    assert all(l[3] == "False" and l[4] == "True" for l in lines)       # one "no" vote is "no" everywhere
