@@ -58,10 +58,6 @@ class TTTdInput(C.Structure):
                 ("y_out", C.c_void_p), ("q_out", C.c_void_p), ("step_dev", C.c_void_p), ("window_dev", C.c_void_p)]
 
 
-class TTDqdaInput(C.Structure):
-    _fields_ = [("critic", C.POINTER(TTMlpWeights)), ("q_out", C.c_void_p), ("dq_da", C.c_void_p)]
-
-
 class TTSideBuffer(C.Structure):
     _fields_ = [("obs", C.c_void_p), ("act", C.c_void_p), ("rew", C.c_void_p), ("obs2", C.c_void_p), ("done", C.c_void_p),
                 ("count", C.c_int32), ("reserved_", C.c_int32)]
@@ -135,11 +131,11 @@ _SIGNATURES = {
     "tt_critic_head_td": (C.c_int, [_I, _P, _P, C.POINTER(TTMlpWeights), _P, _P, C.c_float, _P, _P, _P, _P]),
     "tt_mlp_backward": (C.c_int, [_I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, C.POINTER(TTMlpWeights),
                                   C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights), C.POINTER(TTTdInput),
-                                  C.POINTER(TTDqdaInput), _P]),
+                                  _P]),
     "tt_mlp_backward_adam": (C.c_int, [_I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, C.POINTER(TTMlpWeights),
                                        C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights), _I, _P, _P, _P,
                                        _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
-                                       C.POINTER(TTTdInput), C.POINTER(TTDqdaInput), _P]),
+                                       C.POINTER(TTTdInput), _P]),
     "tt_mlp_backward_rows_pair": (C.c_int, [_I, C.c_float, _P, C.POINTER(TTMlpWeights), C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs),
                                             C.POINTER(TTTdInput), _P, C.POINTER(TTMlpWeights), C.POINTER(TTMlpSaved),
                                             C.POINTER(TTMlpBwdWs), _P]),

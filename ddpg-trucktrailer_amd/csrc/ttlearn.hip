@@ -10,8 +10,6 @@
 //   k_bwd_weights         dW2 = dX2^T * H1 and dW1 = dX1^T * S on the MFMA (K = batch), all bias / LayerNorm / head
 //                         gradients as deterministic column sums (no atomics), then (one rank) torch.optim.Adam's
 //                         update + the soft target update on each element just finished
-//   k_actor_rows          the actor's step through the updated critic for a workgroup's rows: Q(s, mu(s)) with dQ/da
-//                         (critic forward), then the actor's per-row backward
 //   k_adam_soft           Adam + soft update as a launch of its own (data-parallel ranks: after the all-reduce);
 //   k_head_td, k_td_target  the TD target as launches of their own
 //
@@ -839,25 +837,6 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows_pair(const int n, const fl
     }
 }
 
-// The actor's step through the updated critic (DDPG_agent.py:100-103) for the 16 rows of a workgroup in ONE launch:
-// Q(s, mu(s)) with dQ/da on the critic (forward only), then the actor's per-row backward with d(loss)/d(mu) =
-// scale * dQ/da.  Both halves partition the batch by the same rows, so nothing crosses workgroups between them.
-__global__ __launch_bounds__(64 * NW) void k_actor_rows(const int n, const float scale, const float *__restrict__ obs,
-                                                    const float *__restrict__ mu, const Weights Wc, float *__restrict__ q_out,
-                                                    float *__restrict__ dq_da, const Weights Wa, const Saved sv_actor,
-                                                    const BwdOut o) {
-    __shared__ __attribute__((aligned(16))) float tile[H1S_FLOATS];     // the forward's h1 tile
-    __shared__ __attribute__((aligned(16))) float tile2[DXS_FLOATS];    // the forward's fc2 tile, then the backward's dX2 tile
-    __shared__ float red[NW * TR];
-    __shared__ float rsc_s[TR];
-    const int row0 = blockIdx.x * TR;
-    const Saved none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    fwd_small_body<true>(n, obs, mu, Wc, q_out, none, dq_da, nullptr, tile, tile2, row0);
-    __syncthreads();                                   // dq_da of these rows (global) and the tiles are handed over
-    const TdIn td{};
-    bwd_rows_body<false>(n, 2, scale, nullptr, mu, nullptr, dq_da, Wa, sv_actor, o, td, tile2, red, rsc_s, row0);
-}
-
 // ------------------------------------------------------------------------------------------------------
 // weight gradients.  Workgroup roles by blockIdx; K = batch in permuted k16 steps, SPLIT over the 4 waves of the
 // workgroup (each wave takes a quarter of the batch rows, all its loads are independent and issued together), the
@@ -1337,11 +1316,10 @@ int tt_critic_head_td(int n, const float *z_state, const float *action, const tt
 static int backward_impl(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
                          const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
                          const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const AdamFused &A,
-                         const tt_td_input *tdi, const tt_dqda_input *dqi, tt_stream_t stream) {
+                         const tt_td_input *tdi, tt_stream_t stream) {
     if (n <= 0 || !obs || !out || !ok_shape(w, critic != 0) || !ok_shape(grads, critic != 0) || !saved || !ws ||
-        (critic && !action) || mode < 0 || mode > 2 || (mode == 0 && !d_out) || (mode == 1 && !y && !tdi) || (mode == 2 && !aux && !dqi))
+        (critic && !action) || mode < 0 || mode > 2 || (mode == 0 && !d_out) || (mode == 1 && !y && !tdi) || (mode == 2 && !aux))
         return TT_EINVAL;
-    if (dqi && (critic || mode != 2 || !ok_shape(dqi->critic, true) || !dqi->q_out || !dqi->dq_da)) return TT_EINVAL;
     TdIn td{};
     if (tdi) {
         const tt_mlp_weights *tw = tdi->target_critic;
@@ -1361,9 +1339,6 @@ static int backward_impl(int n, int critic, int mode, float scale, const float *
     if (critic)
         hipLaunchKernelGGL(k_bwd_rows<true>, grid, block_rows, 0, stream, n, mode, scale, d_out, out, y, aux,
                            to_weights(w), sv, o, td);
-    else if (dqi)
-        hipLaunchKernelGGL(k_actor_rows, grid, block_rows, 0, stream, n, scale, obs, out, to_weights(dqi->critic), dqi->q_out,
-                           dqi->dq_da, to_weights(w), sv, o);
     else
         hipLaunchKernelGGL(k_bwd_rows<false>, grid, block_rows, 0, stream, n, mode, scale, d_out, out, y, aux,
                            to_weights(w), sv, o, td);
@@ -1389,9 +1364,9 @@ static Grads to_grads(const tt_mlp_weights *g) {
 int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
                     const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
                     const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const tt_td_input *td,
-                    const tt_dqda_input *dq, tt_stream_t stream) {
+                    tt_stream_t stream) {
     AdamFused A{};
-    return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, td, dq, stream);
+    return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, td, stream);
 }
 
 int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
@@ -1399,7 +1374,7 @@ int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *
                          const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, int count,
                          float *const *params, float *const *exp_avg, float *const *exp_avg_sq, float *const *targets,
                          const int64_t *step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
-                         float tau, const tt_td_input *td, const tt_dqda_input *dq, tt_stream_t stream) {
+                         float tau, const tt_td_input *td, tt_stream_t stream) {
     if (count != (critic ? 12 : 10) || !params || !exp_avg || !exp_avg_sq || !step_dev) return TT_EINVAL;
     AdamFused A{};
     for (int i = 0; i < count; ++i) {
@@ -1409,7 +1384,7 @@ int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *
     A.step_dev = reinterpret_cast<const long long *>(step_dev);
     A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.weight_decay = weight_decay; A.tau = tau;
     A.on = 1;
-    return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, td, dq, stream);
+    return backward_impl(n, critic, mode, scale, obs, action, d_out, out, y, aux, w, saved, ws, grads, A, td, stream);
 }
 
 int tt_mlp_backward_rows_pair(int n, float scale_critic, const float *q_out, const tt_mlp_weights *critic,

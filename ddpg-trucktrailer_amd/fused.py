@@ -18,6 +18,8 @@ def _ptr(t):
 
 
 def supported(net):
+    if not all(hasattr(net, a) for a in ("fc1", "fc2", "bn1", "bn2")) or not (hasattr(net, "mu") or hasattr(net, "q")):
+        return False          # a module of another structure: the callers use it through torch
     return (net.fc1.weight.is_cuda and net.fc1.weight.dtype == torch.float32 and tuple(net.fc1.weight.shape) == (400, 23)
             and tuple(net.fc2.weight.shape) == (300, 400) and net.bn1.eps == 1e-5 and net.bn2.eps == 1e-5)
 
@@ -80,10 +82,17 @@ def packed_weights_of(net, index, max_workgroups=None, capped_grids=None, two_im
     key = tuple(p.data_ptr() for p in net.parameters())
     hit = cache.get(index)
     if hit is None or hit[0] != key:
+        # (parameter storage replaced: a new struct -- with everything the old one had been given, the second image
+        # included, so that a pack() that follows writes the parity a later policy launch reads; a loop that captured
+        # launches of the old struct re-captures: DDPGRollout watches the key through packed_key_of)
+        old = hit[1] if hit is not None else None
         w = _fill_weights(net, L.TTMlpWeights())
         ws = torch.empty(int(L.load().tt_mlp_split_ws_bytes()), dtype=torch.uint8, device=net.fc2.weight.device)
         w.split_ws, w.ws_packed = ws.data_ptr(), 1
         hit = cache[index] = (key, w, ws)
+        if old is not None:
+            w.max_workgroups, w.capped_grids = old.max_workgroups, old.capped_grids
+            two_images = two_images or bool(old.split_ws_alt)
     if max_workgroups is not None:
         hit[1].max_workgroups = int(max_workgroups)
     if capped_grids is not None:
@@ -94,6 +103,12 @@ def packed_weights_of(net, index, max_workgroups=None, capped_grids=None, two_im
         hit[1].split_ws_alt = alt.data_ptr()
         cache[index] = hit + (alt,)
     return hit[1]
+
+
+def packed_key_of(net):
+    """What packed_weights_of() keys its structs on (the parameters' storages): a loop that captured launches of a struct
+    compares this before it replays them."""
+    return tuple(p.data_ptr() for p in net.parameters())
 
 
 def pack(net, index, bump=None, cursor=None):

@@ -160,22 +160,21 @@ class FusedLearner:
                                              C.byref(self.w(net)), _p(out), C.byref(saved) if saved else None,
                                              _p(dq_da), self._stream()))
 
-    def _bwd(self, st, mode, scale, obs, action, out, y=None, aux=None, td=None, dq=None):
+    def _bwd(self, st, mode, scale, obs, action, out, y=None, aux=None, td=None):
         self._fresh()
         L.check(self.lib.tt_mlp_backward(self.B, 1 if st.critic else 0, mode, float(scale), _p(obs), _p(action), None,
                                          _p(out), _p(y), _p(aux), C.byref(self.w(st.net)), C.byref(st.saved),
                                          C.byref(self.ws), C.byref(st.gstruct), C.byref(td) if td is not None else None,
-                                         C.byref(dq) if dq is not None else None, self._stream()))
+                                         self._stream()))
 
-    def _bwd_adam(self, st, hyp, tau, mode, scale, obs, action, out, y=None, aux=None, td=None, dq=None):
+    def _bwd_adam(self, st, hyp, tau, mode, scale, obs, action, out, y=None, aux=None, td=None):
         """_bwd + _adam in the backward's own two launches (include/ttenv.h: tt_mlp_backward_adam)."""
         lr, b1, b2, eps, wd = hyp
         L.check(self.lib.tt_mlp_backward_adam(self.B, 1 if st.critic else 0, mode, float(scale), _p(obs), _p(action), None,
                                               _p(out), _p(y), _p(aux), C.byref(self.w(st.net)),
                                               C.byref(st.saved), C.byref(self.ws), C.byref(st.gstruct), st.count, st.a_p,
                                               st.a_m, st.a_v, st.a_t, _p(self.step_dev), lr, b1, b2, eps, wd, tau,
-                                              C.byref(td) if td is not None else None,
-                                              C.byref(dq) if dq is not None else None, self._stream()))
+                                              C.byref(td) if td is not None else None, self._stream()))
         if self.use_images:            # this (older) entry point does not maintain images: make them again before the next use
             self._img_seen[id(st.net)] = self._img_seen[id(st.target)] = None
 

@@ -152,8 +152,12 @@ class TrajectoryRing:
                 else:
                     for k, v in sd["side"].items():
                         self.side[k].copy_(v)
-                self.side_count = int(sd.get("side_count", 0))
-                self.side_epoch += 1
+        # the side buffer's count always follows the checkpoint: a file without side tuples (or saved with_replay=False)
+        # must not leave this ring's older tuples in the draw; captured launches bake the count, so the epoch moves with it
+        count = int(sd.get("side_count", 0)) if ("obs" in sd and "side" in sd) else 0
+        if count != self.side_count:
+            self.side_count = count
+            self.side_epoch += 1
         self.k = int(sd["k"])               # the counters come back whether or not the contents did
         self.k_dev.fill_(self.k)
 

@@ -299,7 +299,9 @@ class DDPGRollout:
         self.graph = self.graph1 = self.graphG = self.graphM = self.dp_graphs = None
 
     def _check_epoch(self):
-        epoch = (getattr(self.env, "graph_epoch", 0), self.ring.side_epoch)
+        # (the actor's parameter storages are part of it: the policy's packed-image struct is keyed on them, fused.py)
+        epoch = (getattr(self.env, "graph_epoch", 0), self.ring.side_epoch,
+                 fused.packed_key_of(self.agent.actor) if self.fused_act else None)
         if self._graph_epoch != epoch:
             if self._graph_epoch is not None:
                 self.invalidate_graphs()

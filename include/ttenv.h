@@ -387,17 +387,10 @@ typedef struct tt_td_input {
     int64_t *window_dev;   /* optional: a second device counter advanced by 1 -- the sampling-window counter of a pipelined
                               loop (tt_ring_sample's k_dev), moved on by the last learn() of a vector step */
 } tt_td_input;
-/* dq (optional, actor with mode 2 only; aux may then be NULL): the critic forward that produces aux = dQ/da done in the
- * actor's per-row backward launch -- Q(s, out) on `critic` for the same rows (DDPG_agent.py:101-102), q_out [n] and
- * dq_da [n] written out, then the backward with d(loss)/d(out) = scale * dq_da. */
-typedef struct tt_dqda_input {
-    const tt_mlp_weights *critic;
-    float *q_out, *dq_da;
-} tt_dqda_input;
 int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
                     const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
                     const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const tt_td_input *td,
-                    const tt_dqda_input *dq, tt_stream_t stream);
+                    tt_stream_t stream);
 
 /* tt_mlp_backward with the optimizer step of tt_adam_soft_update applied in the weight-gradient launch itself (each
  * gradient element is finished by exactly one workgroup, which then updates that parameter, its Adam moments and its
@@ -409,7 +402,7 @@ int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *
                          const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, int count,
                          float *const *params, float *const *exp_avg, float *const *exp_avg_sq, float *const *targets,
                          const int64_t *step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
-                         float tau, const tt_td_input *td, const tt_dqda_input *dq, tt_stream_t stream);
+                         float tau, const tt_td_input *td, tt_stream_t stream);
 
 /* learn()'s second phase in the form the rollout loop uses.  The actor's per-row backward is linear in the row's
  * d(loss)/d(pre-tanh) = -(1/B) dQ/da (1 - mu^2), and only dQ/da needs the UPDATED critic (DDPG_agent.py:100-103): so

@@ -320,25 +320,32 @@ def test_whole_loop_resume_is_bitwise(gpu_device, tmp_path):
     a.env.close(); b.env.close()
 
 
-def test_whole_config3_loop_at_bench_size(gpu_device):
-    """BASELINE config 3 at its stated size (N = 65536, batch 256, 64-slot ring): 8 steps as graphs == 8 eager steps,
-    finite weights, learn() really ran."""
+@pytest.mark.parametrize("graph_steps,steps", [(4, 12), (20, 28)])
+def test_whole_config3_loop_at_bench_size(gpu_device, graph_steps, steps):
+    """BASELINE config 3 at its stated size (N = 65536, batch 256, 64-slot ring): the steps as graphs == the same number of
+    eager steps bit for bit, finite weights, learn() really ran, both device counters in step.  graph_steps = 20 is THE graph
+    bench.py's headline number replays -- 20 whole steps, three capped policy grids per step beside learn()'s launches on
+    the second chain: 4 eager warm-up steps, then one 20-step graph and one 4-step graph."""
     import torch
     from ddpg_trucktrailer_amd.rollout import DDPGRollout
     from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
     n = 65536
     flats = []
-    for graph_steps in (4, 0):
+    for g in (graph_steps, 0):
         env = TruckTrailerVecEnv(n)
         env.reset(seed=27)
-        loop = DDPGRollout(env, batch_size=256, replay_slots=64, seed=27, graph_steps=graph_steps)
+        loop = DDPGRollout(env, batch_size=256, replay_slots=64, seed=27, graph_steps=g)
         w0 = _loop_flat(loop).clone()
-        loop.run(12)                   # 4 eager warm-up steps + 8
+        loop.run(steps)                # 4 eager warm-up steps + the graphs
         torch.cuda.synchronize()
+        if g:
+            assert loop.graphG is not None and (loop.graphM is not None) == (g > 4)
         flat = _loop_flat(loop)
         assert torch.isfinite(flat).all() and not torch.equal(flat, w0)
-        assert torch.isfinite(loop.ring.rew[:12]).all() and int(loop.learner.step_dev.item()) == 10
-        flats.append((flat.clone(), loop.ring.obs[:13].clone(), loop.env.state.clone()))
+        assert torch.isfinite(loop.ring.rew[:steps]).all() and int(loop.learner.step_dev.item()) == steps - 2
+        assert int(loop.ring.k_dev.item()) == steps and int(loop.k_pipe_dev.item()) == steps
+        flats.append((flat.clone(), loop.ring.obs[:steps + 1].clone(), loop.ring.act[:steps].clone(), loop.env.state.clone(),
+                      loop.noise.x.clone()))
         env.close()
         del loop
     for x, y in zip(*flats):
