@@ -83,9 +83,15 @@ __device__ unsigned long long g_stamps[32];
 __device__ unsigned long long g_blk[512][2];
 #define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_stamps[i] = wall_clock64(); g_stamps[16 + i] = clock64(); } } while (0)
 #define STAMPB(i, blk0) do { if ((int)blockIdx.x == (blk0) && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+// begin / end of every workgroup of learn()'s launches: [kernel][block][2] (tools/learn_blocks.py)
+__device__ unsigned long long g_kblk[6][512][2];
+#define KBEGIN(k) do { if (threadIdx.x == 0 && blockIdx.x < 512) g_kblk[k][blockIdx.x][0] = wall_clock64(); } while (0)
+#define KEND(k) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 512) g_kblk[k][blockIdx.x][1] = wall_clock64(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #define STAMPB(i, blk0) do { } while (0)
+#define KBEGIN(k) do { } while (0)
+#define KEND(k) do { } while (0)
 #endif
 
 // __restrict__ on the members: none of these buffers alias, and without it every store (saved activations,
@@ -471,7 +477,9 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_small(const int n, const float 
                                                    float *__restrict__ z_state) {
     __shared__ __attribute__((aligned(16))) float h1_s[H1S_FLOATS];
     __shared__ __attribute__((aligned(16))) float z_s[TR * DS];
+    KBEGIN(3);
     fwd_small_body<CRITIC>(n, obs, action, W, out, sv, dq_da, z_state, h1_s, z_s, blockIdx.x * TR);
+    KEND(3);
 }
 
 // Up to four independent forwards on the same number of rows in ONE launch (workgroup b serves job b / blocks_per_job):
@@ -495,8 +503,10 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
     __shared__ __attribute__((aligned(16))) float z_s[TR * DS];
     const int job = blockIdx.x / J.blocks_per_job, row0 = (blockIdx.x - job * J.blocks_per_job) * TR;
     const FwdJob &q = J.j[job];
+    KBEGIN(0);
     if (q.critic) fwd_small_body<true>(J.n, q.obs, q.action, q.W, q.out, q.sv, q.dq_da, q.z_state, h1_s, z_s, row0);
     else fwd_small_body<false>(J.n, q.obs, q.action, q.W, q.out, q.sv, nullptr, nullptr, h1_s, z_s, row0);
+    KEND(0);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -828,6 +838,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows_pair(const int n, const fl
     __shared__ float red[NW * TR];
     __shared__ float rsc_s[TR];
     const int nb = (n + TR - 1) / TR;
+    KBEGIN(1);
     if ((int)blockIdx.x < nb) {
         bwd_rows_body<true>(n, 1, scale_c, nullptr, q_out, nullptr, nullptr, Wc, sv_c, o_c, td, dx2_s, red, rsc_s, blockIdx.x * TR);
     } else {
@@ -835,6 +846,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows_pair(const int n, const fl
         bwd_rows_body<false>(n, 3, 1.f, nullptr, mu_out, nullptr, nullptr, Wa, sv_a, o_a, none, dx2_s, red, rsc_s,
                              ((int)blockIdx.x - nb) * TR);
     }
+    KEND(1);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -928,6 +940,7 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
         bc1 = (float)(1.0 - pow((double)A.beta1, t));
         sqrt_bc2 = sqrtf((float)(1.0 - pow((double)A.beta2, t)));
     }
+    KBEGIN(ROWSCALE ? 4 : 2);
     STAMPB(12, 0); STAMPB(14, NU2); STAMPB(5, NU2 + NU1);
 #ifdef TT_STAMPS
     if (threadIdx.x == 0) g_blk[blockIdx.x][0] = wall_clock64();
@@ -1145,6 +1158,7 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
         __syncthreads(); if (threadIdx.x == 0) g_blk[blockIdx.x][1] = wall_clock64();
 #endif
     }
+    KEND(ROWSCALE ? 4 : 2);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1483,6 +1497,9 @@ int tt_mlp_fc2_image_pack(const tt_mlp_weights *w, tt_stream_t stream) {
 #ifdef TT_STAMPS
 int tt_debug_blocks(unsigned long long *out1024) {
     return hipMemcpyFromSymbol(out1024, HIP_SYMBOL(g_blk), sizeof(unsigned long long) * 1024) == hipSuccess ? 0 : -3;
+}
+int tt_debug_kblocks(unsigned long long *out6x1024) {
+    return hipMemcpyFromSymbol(out6x1024, HIP_SYMBOL(g_kblk), sizeof(unsigned long long) * 6 * 1024) == hipSuccess ? 0 : -3;
 }
 int tt_debug_stamps(unsigned long long *out32) {
     return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -3;

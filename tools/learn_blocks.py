@@ -1,0 +1,81 @@
+"""GPU (TT_STAMPS build of the library, TT_LIB_PATH): where the time of ONE learn() goes, from wall-clock stamps (100 MHz) at
+the begin and end of EVERY workgroup of its five launches -- alone on the chip (eager launches back to back) and inside the
+N-env loop (eager pipelined steps: the policy's capped grids run beside it).  Prints, per launch and relative to the first
+workgroup of the first launch: first / last workgroup start, first / last workgroup end, median workgroup duration, and the
+gap from the previous launch's last end to this launch's first start (the kernel boundary as the workgroups see it)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from ddpg_trucktrailer_amd import _lib as L
+from ddpg_trucktrailer_amd.agent import Agent
+from ddpg_trucktrailer_amd.fused_learn import FusedLearner
+
+NAMES = ["k_fwd_multi", "k_bwd_rows_pair", "k_bwd_weights<critic>", "k_fwd_small<critic>", "k_bwd_weights<actor>"]
+GRID = [64, 32, 133 + 25 + 57, 16, 133 + 25 + 47]
+
+
+def read(lib):
+    buf = (C.c_ulonglong * (6 * 1024))()
+    assert lib.tt_debug_kblocks(buf) == 0
+    return np.array(buf, dtype=np.int64).reshape(6, 512, 2)
+
+
+def report(a, title):
+    print(title)
+    t0 = a[0, :GRID[0], 0].min()
+    prev_end = None
+    for k, (name, g) in enumerate(zip(NAMES, GRID)):
+        st, en = (a[k, :g, 0] - t0) / 100.0, (a[k, :g, 1] - t0) / 100.0
+        gap = "" if prev_end is None else f"  gap after previous launch {st.min() - prev_end:5.2f}"
+        print(f"  {name:24s} {g:3d} wgs  start {st.min():6.2f}..{st.max():6.2f}  end {en.min():6.2f}..{en.max():6.2f}  "
+              f"median wg {np.median(en - st):5.2f}  max wg {np.max(en - st):5.2f}{gap}")
+        prev_end = en.max()
+    print(f"  chain: first start -> last end {prev_end:6.2f} us")
+
+
+def main():
+    dev = torch.device("cuda:0")
+    lib = L.load()
+    B = 256
+    ag = Agent(1e-4, 1e-3, (23,), 1e-3, 1, batch_size=B, device=dev, replay=False)
+    fl = FusedLearner(ag, B)
+    s = torch.rand((B, 23), device=dev); a = torch.rand((B, 1), device=dev); r = torch.rand(B, device=dev)
+    d8 = torch.zeros(B, dtype=torch.uint8, device=dev)
+    for _ in range(20):
+        fl.learn_batch(s, a, r, s, d8)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        fl.learn_batch(s, a, r, s, d8)
+        torch.cuda.synchronize()
+        report(read(lib), f"learn() alone on the chip, eager launches (repeat {rep})")
+    # captured: the same five launches as one hipGraph
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=side):
+        fl.learn_batch(s, a, r, s, d8)
+    torch.cuda.current_stream().wait_stream(side)
+    for rep in range(3):
+        g.replay(); g.replay(); g.replay()
+        torch.cuda.synchronize()
+        report(read(lib), f"learn() alone, third of three back-to-back hipGraph replays (repeat {rep})")
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    env = TruckTrailerVecEnv(n); env.reset(seed=27)
+    loop = DDPGRollout(env, batch_size=256, replay_slots=64, seed=27, graph_steps=20)
+    loop.run(4 + 20 + 4 + 1)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        loop.run(20)
+        torch.cuda.synchronize()
+        report(read(lib), f"learn() of the LAST step of a 20-step graph of the N = {n} loop (policy grids beside it) (repeat {rep})")
+
+
+if __name__ == "__main__":
+    main()
