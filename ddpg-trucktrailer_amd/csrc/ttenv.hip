@@ -34,6 +34,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -127,6 +128,7 @@ struct KParams {
     int npad;  // envs rounded up to a whole tile: row stride of the cold block
     int stateless;       // simv1.py:435: the reward carries nothing from step to step
     int pool_m;          // > 0: resets draw from pool[pool_m][3] instead of the box rlo..rhi
+    int nt;              // 1: obs / reward / done leave as non-temporal stores (set by N: see nt_stores_for)
     const double *pool;
 #if TT_TABLE
     KTable t;
@@ -298,7 +300,12 @@ __device__ __forceinline__ void observe(const KParams &P, const Goal &g, double 
 
 // Store a workgroup's [nv,23] f32 observation tile, staged through LDS so the global stores are
 // contiguous 16-byte vectors.  Every thread of the block must call this (barriers inside).
-__device__ inline void store_obs_tile(float *tile, const float *of, bool valid, float *obs, int block_first, int nv) {
+// nt: non-temporal stores -- at env counts whose per-step traffic is far beyond the caches, the 97 B per env-step that nobody
+// re-reads before they are evicted anyway (observation, reward, done: ~half of all written bytes) stop displacing the state
+// tiles on their way out: 278 -> 248 us per launch at 4 M envs (0.59 -> 0.66 of 8 TB/s), nothing at 65,536 / 1 M envs, where
+// the policy's next launch finds the observations in L2 / the Infinity Cache (profiles/r03_nsweep.md).
+__device__ inline void store_obs_tile(float *tile, const float *of, bool valid, float *obs, int block_first, int nv,
+                                      const bool nt = false) {
     const int tid = threadIdx.x;
     if (valid) {
 #pragma unroll
@@ -311,7 +318,15 @@ __device__ inline void store_obs_tile(float *tile, const float *of, bool valid, 
         const int nvec = total >> 2;
         const float4 *t4 = reinterpret_cast<const float4 *>(tile);
         float4 *d4 = reinterpret_cast<float4 *>(dst);
-        for (int q = tid; q < nvec; q += BLOCK) d4[q] = t4[q];
+        if (nt) {
+            using v4f = __attribute__((ext_vector_type(4))) float;
+            for (int q = tid; q < nvec; q += BLOCK) {
+                const float4 t = t4[q];
+                __builtin_nontemporal_store(v4f{t.x, t.y, t.z, t.w}, reinterpret_cast<v4f *>(d4 + q));
+            }
+        } else {
+            for (int q = tid; q < nvec; q += BLOCK) d4[q] = t4[q];
+        }
         for (int q = (nvec << 2) + tid; q < total; q += BLOCK) dst[q] = tile[q];
     } else {
         for (int q = tid; q < total; q += BLOCK) dst[q] = tile[q];
@@ -664,8 +679,13 @@ __global__ __launch_bounds__(BLOCK) void k_step(const KParams P, const int n, co
 #else
         step_env(P, e, a, of, o);
 #endif
-        reward[i] = (float)o.total;
-        done[i] = o.done ? 1 : 0;
+        if (P.nt) {
+            __builtin_nontemporal_store((float)o.total, reward + i);
+            __builtin_nontemporal_store((uint8_t)(o.done ? 1 : 0), done + i);
+        } else {
+            reward[i] = (float)o.total;
+            done[i] = o.done ? 1 : 0;
+        }
         if (INFO) write_info(info, (size_t)n, i, e, o);
         if (AUTO_RESET && o.done) {
             const uint32_t ep = b.episodes[i] + 1u;
@@ -677,7 +697,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(const KParams P, const int n, co
         }
         store_env(b, i, e);
     }
-    store_obs_tile(tile, of, valid, obs, block_first, nv);
+    store_obs_tile(tile, of, valid, obs, block_first, nv, P.nt != 0);
 }
 
 // K vector steps in ONE launch with the random policy: the env stays in registers, only the last
@@ -913,6 +933,16 @@ int fail(tt_env *e, int code, const char *fmt, ...) {
         if (err_ != hipSuccess) return fail((e), TT_EHIP, "%s: %s", #call, hipGetErrorString(err_)); \
     } while (0)
 
+// Non-temporal obs / reward / done stores from this many envs on: a step then writes > 200 MB, past every cache level
+// (TT_NT_ENVS overrides: 0 = never, 1 = always).
+inline int nt_stores_for(int npad) {
+    static const long long thr = [] {
+        const char *e = std::getenv("TT_NT_ENVS");
+        return e ? std::atoll(e) : 2097152ll;
+    }();
+    return thr > 0 && npad >= thr ? 1 : 0;
+}
+
 KParams make_kparams(const tt_params &p, int npad) {
     KParams k{};
     k.v = p.v1x;
@@ -938,6 +968,7 @@ KParams make_kparams(const tt_params &p, int npad) {
     k.stateless = p.stateless_reward;
     k.pool_m = 0;
     k.pool = nullptr;
+    k.nt = nt_stores_for(npad);
 #if TT_TABLE
     k.t = make_table();
 #endif

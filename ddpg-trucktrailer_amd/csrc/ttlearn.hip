@@ -83,6 +83,8 @@ __device__ unsigned long long g_stamps[32];
 __device__ unsigned long long g_blk[512][2];
 #define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_stamps[i] = wall_clock64(); g_stamps[16 + i] = clock64(); } } while (0)
 #define STAMPB(i, blk0) do { if ((int)blockIdx.x == (blk0) && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+__device__ unsigned long long g_wst[2][16];     // phase stamps of workgroup 0 of k_bwd_weights<critic / actor>
+#define WST(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_wst[ROWSCALE ? 1 : 0][i] = wall_clock64(); } while (0)
 // begin / end of every workgroup of learn()'s launches: [kernel][block][2] (tools/learn_blocks.py)
 __device__ unsigned long long g_kblk[6][512][2];
 #define KBEGIN(k) do { if (threadIdx.x == 0 && blockIdx.x < 512) g_kblk[k][blockIdx.x][0] = wall_clock64(); } while (0)
@@ -92,6 +94,7 @@ __device__ unsigned long long g_kblk[6][512][2];
 #define STAMPB(i, blk0) do { } while (0)
 #define KBEGIN(k) do { } while (0)
 #define KEND(k) do { } while (0)
+#define WST(i) do { } while (0)
 #endif
 
 // __restrict__ on the members: none of these buffers alias, and without it every store (saved activations,
@@ -141,22 +144,40 @@ __device__ __forceinline__ float wave_max64(float v) {
                  fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(u, 48))));
 }
 
-// combine a per-wave, per-row partial (valid in every lane of the 16-lane group of that row) across the 4 waves.
-// red: [NW waves][16 rows].  Two barriers; every lane returns the total of ITS four rows (r = 0..3).
-__device__ __forceinline__ void cross_wave_sum(float *red, int wave, int l4, int l15, float (&v)[4]) {
-    __syncthreads();                       // previous use of `red` is over
+// Workgroup barrier that publishes LDS only.  __syncthreads() also drains every outstanding GLOBAL store of the wave
+// (s_waitcnt vmcnt(0) in front of s_barrier): the learn() kernels store their saved activations / per-row gradients right
+// before their barriers, and each such barrier then cost a store round trip (~1-2 us) that nothing in the workgroup waits for.
+// No launch here hands global data from one wave to another of the same workgroup; loads in flight stay tracked by the
+// compiler (it waits at their first use).
+__device__ __forceinline__ void lds_barrier() {
+#ifdef TT_DBG_FULL_BARRIER
+    __syncthreads();
+    return;
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// combine two per-wave, per-row partials (valid in every lane of the 16-lane group of that row) across the waves.
+// red: [2][NW waves][16 rows].  Two barriers for both; every lane returns the totals of ITS four rows (r = 0..3).
+__device__ __forceinline__ void cross_wave_sum2(float *red, int wave, int l4, int l15, float (&v)[4], float (&w2)[4]) {
+    lds_barrier();                         // previous use of `red` is over
     if (l15 == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave * TR + l4 * 4 + r] = v[r];
+        for (int r = 0; r < 4; ++r) {
+            red[wave * TR + l4 * 4 + r] = v[r];
+            red[NW * TR + wave * TR + l4 * 4 + r] = w2[r];
+        }
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = l4 * 4 + r;
-        float t = 0.f;
+        float t = 0.f, u = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) t += red[w * TR + row];
-        v[r] = t;
+        for (int w = 0; w < NW; ++w) { t += red[w * TR + row]; u += red[NW * TR + w * TR + row]; }
+        v[r] = t; w2[r] = u;
     }
 }
 
@@ -243,7 +264,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
             for (int r = 0; r < 4; ++r) h1_s[(l4 * 4 + r) * HS1 + t * 16 + l15] = acc1[i][r];
         }
     }
-    __syncthreads();
+    lds_barrier();
     // bias, LayerNorm(400) (biased variance, eps 1e-5), ReLU for this wave's two rows.  With an fc2 image the rows leave as
     // the two f16 planes of the layer-2 operand, which share the buffer with the f32 tile: every wave has read its rows
     // before any plane is written
@@ -259,7 +280,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
             xr[rr][i] = c < H1 ? h1_s[lr * HS1 + c] + pb1[i] : 0.f;
         }
     }
-    if (img) __syncthreads();
+    if (img) lds_barrier();
 #pragma unroll
     for (int rr = 0; rr < TR / NW; ++rr) {
         const int lr = wave * (TR / NW) + rr, row = row0 + lr;
@@ -302,7 +323,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
             }
         }
     }
-    __syncthreads();   // the 16 x 400 activation tile is complete
+    lds_barrier();   // the 16 x 400 activation tile is complete
     STAMP(2);
 
     // ---- layer 2: this wave's column tiles t = wave, wave+NW, ... (3 or 2 of the 20); A from the LDS tile (one
@@ -402,7 +423,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
             for (int r = 0; r < 4; ++r) z_s[(l4 * 4 + r) * DS + col] = acc2[i][r];
         }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- epilogue for this wave's two rows: bias, LayerNorm(300), (critic: + action_value(a)), ReLU, head
     float avs[TR / NW];                                    // loaded before the first row's stores (see k_bwd_rows, phase A)
 #pragma unroll
@@ -546,7 +567,7 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
                                               float *__restrict__ dx2_s, float *__restrict__ red, float *__restrict__ rsc_s,
                                               const int row0) {
     // dx2_s [16][308]: A operand of phase B (with an fc2 image: its two f16 planes [2][16][328], each row scaled by a power
-    // of two whose inverse / 64 goes to rsc_s [16]); red [NW][16]: cross-wave reductions
+    // of two whose inverse / 64 goes to rsc_s [16]); red [2][NW][16]: cross-wave reductions
     const bool img = W.img != nullptr;                     // (uniform over the launch)
     _Float16 *const dxp_s = reinterpret_cast<_Float16 *>(dx2_s);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
@@ -665,7 +686,7 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
         }
         if (lane == 0 && ok) o.dpre[row] = dpre;
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(9);
     // ---- phase B: dH1 [16,400] = dX2 [16,304] * W2 [304,400].  Wave w (< 7) owns the 64-column group w; within the
     // group, output tile t holds columns c0 + 4*(l&15) + t (one float4 of a W2 row feeds the 4 tiles).
@@ -797,8 +818,7 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[r] = row_sum16(s1[r]); s2[r] = row_sum16(s2[r]); }
-    cross_wave_sum(red, wave, l4, l15, s1);
-    cross_wave_sum(red, wave, l4, l15, s2);
+    cross_wave_sum2(red, wave, l4, l15, s1, s2);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = row0 + l4 * 4 + r;
@@ -819,7 +839,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows(const int n, const int mod
                                                       const float *__restrict__ y, const float *__restrict__ aux,
                                                       const Weights W, const Saved sv, const BwdOut o, const TdIn td) {
     __shared__ __attribute__((aligned(16))) float dx2_s[DXS_FLOATS];
-    __shared__ float red[NW * TR];
+    __shared__ float red[2 * NW * TR];
     __shared__ float rsc_s[TR];
     bwd_rows_body<CRITIC>(n, mode, scale, d_out, out, y, aux, W, sv, o, td, dx2_s, red, rsc_s, blockIdx.x * TR);
 }
@@ -835,7 +855,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows_pair(const int n, const fl
                                                            const float *__restrict__ mu_out, const Weights Wa, const Saved sv_a,
                                                            const BwdOut o_a) {
     __shared__ __attribute__((aligned(16))) float dx2_s[DXS_FLOATS];
-    __shared__ float red[NW * TR];
+    __shared__ float red[2 * NW * TR];
     __shared__ float rsc_s[TR];
     const int nb = (n + TR - 1) / TR;
     KBEGIN(1);
@@ -894,9 +914,23 @@ __device__ __forceinline__ float2 adam_finish(const AdamFused &A, const int t, c
     return make_float2(p, tg);
 }
 
-__device__ __forceinline__ void adam_apply(const AdamFused &A, const int t, const size_t i, const float grad,
-                                           const float bc1, const float sqrt_bc2) {
-    adam_finish(A, t, i, grad, adam_load(A, t, i), bc1, sqrt_bc2);
+// the same on one tensor's four arrays picked beforehand (a quantity chosen at run time: indexing the tables of AdamFused
+// with a run-time tensor number keeps all 48 pointers live in scalar registers)
+struct AdamPtrs { float *p, *m, *v, *tgt; };
+__device__ __forceinline__ AdamElem adam_load(const AdamPtrs &q, const size_t i) {
+    return AdamElem{q.p[i], q.m[i], q.v[i], q.tgt ? q.tgt[i] : 0.f};
+}
+__device__ __forceinline__ void adam_finish(const AdamFused &A, const AdamPtrs &q, const size_t i, const float grad, AdamElem e,
+                                            const float bc1, const float sqrt_bc2) {
+    const float g = fmaf(A.weight_decay, e.p, grad);
+    const float m = fmaf(A.beta1, e.m, (1.f - A.beta1) * g);
+    const float v = fmaf(A.beta2, e.v, (1.f - A.beta2) * g * g);
+    q.m[i] = m;
+    q.v[i] = v;
+    const float denom = sqrtf(v) / sqrt_bc2 + A.eps;
+    const float p = e.p - (A.lr / bc1) * (m / denom);
+    q.p[i] = p;
+    if (q.tgt) q.tgt[i] = fmaf(A.tau, p - e.tg, e.tg);
 }
 
 // Optional per-row factor of k_bwd_weights' inputs: row b of dpre / dz / dx2 / dy1 / dx1 (a unit backward, mode 3) counts
@@ -918,78 +952,143 @@ constexpr int NCAT = 10;                            // db2 dg2 dbe2 db1 dg1 dbe1
 constexpr int SUMB_ACTOR = 3 * 5 + 3 * 7 + 5 + 1;   // 64-column chunks per quantity: 300 -> 5, 400 -> 7, 1 -> 1
 constexpr int SUMB_CRITIC = SUMB_ACTOR + 2 * 5;
 
+// Order of events in every workgroup of k_bwd_weights: (1) EVERYTHING it will read is requested at once -- the operands of its
+// first 64 batch rows per wave (the whole batch at 256 rows), the optimizer state of the elements it will finish, the step count;
+// (2) [ROWSCALE] the rows' factors are formed into LDS while those loads fly; (3) products / sums; (4) bias corrections
+// (two f64 pow() -- behind the loads, not in front of them), Adam, soft update, image patch.  Round 2's order (factor table ->
+// barrier -> loop of 16-row steps, each with its own load round trip -> optimizer state loads) cost five dependent memory
+// round trips per workgroup; this one has one.
+constexpr int KCH = 4;                              // k16 steps per chunk of a wave's batch rows
+// (register budget: <= 168, three workgroups per CU -- beside the policy's grid only ~85 CUs are free for the ~205 of this launch)
 template <bool ROWSCALE>
 __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int critic, const float *__restrict__ obs,
                                                      const float *__restrict__ action, const Saved sv,
                                                      const BwdOut d, const Grads G, const AdamFused A, const RowScale RS) {
     __shared__ __attribute__((aligned(16))) float part[4][4][256];     // [wave][tile][lane*4 + r]
     __shared__ float f_s[ROWSCALE ? MAXB : 1];                         // the rows' factors, computed once per workgroup
-    if (ROWSCALE) {
-        for (int b = threadIdx.x; b < n; b += 256) {
-            const float m = RS.mu[b];
-            f_s[b] = RS.scale * RS.dq_da[b] * (1.f - m * m);
+    auto fill_factors = [&]() __attribute__((always_inline)) {       // every thread of the workgroup calls this once
+        if (ROWSCALE) {
+            for (int b = threadIdx.x; b < n; b += 256) {
+                const float m = RS.mu[b];
+                f_s[b] = RS.scale * RS.dq_da[b] * (1.f - m * m);
+            }
+            lds_barrier();
         }
-        __syncthreads();
-    }
-    auto row_factor = [&](const RowScale &, const int b) -> float { return ROWSCALE ? f_s[b] : 1.f; };
+    };
+    auto row_factor = [&](const int b) -> float { return ROWSCALE ? f_s[b] : 1.f; };
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int blk = blockIdx.x;
-    float bc1 = 1.f, sqrt_bc2 = 1.f;
-    if (A.on) {
-        const double t = (double)*A.step_dev;
-        bc1 = (float)(1.0 - pow((double)A.beta1, t));
-        sqrt_bc2 = sqrtf((float)(1.0 - pow((double)A.beta2, t)));
-    }
     KBEGIN(ROWSCALE ? 4 : 2);
     STAMPB(12, 0); STAMPB(14, NU2); STAMPB(5, NU2 + NU1);
 #ifdef TT_STAMPS
     if (threadIdx.x == 0) g_blk[blockIdx.x][0] = wall_clock64();
 #endif
+    long long step_count = 0;
+    if (A.on) step_count = *A.step_dev;
+    auto bias_corrections = [&](float &bc1, float &sqrt_bc2) __attribute__((always_inline)) {
+        bc1 = 1.f; sqrt_bc2 = 1.f;
+        if (A.on) {
+            const double t = (double)step_count;
+            bc1 = (float)(1.0 - pow((double)A.beta1, t));
+            sqrt_bc2 = sqrtf((float)(1.0 - pow((double)A.beta2, t)));
+        }
+    };
     const int rows_w = (((n + 3) / 4) + 15) / 16 * 16;                  // batch rows per wave, whole k16 steps
     const int b_lo = wave * rows_w, b_hi = min(n, b_lo + rows_w);
     if (blk < NU2) {
         const int jt = blk / NG, grp = blk - jt * NG;
         const int j = jt * 16 + l15, c0 = grp * 64 + 4 * l15;
         const bool jok = j < H2, cok = c0 < H1;
+        const int col = grp * 64 + 4 * l15 + wave;                       // wave w finishes output tile t = w: columns c0 + t
+        const bool own = col < H1 && grp * 64 + 4 * l15 < H1;
         f32x4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
-            float av[4];
-            float4 bv[4];
+        float av[KCH][4];
+        float4 bv[KCH][4];
+        // unconditional loads from clamped (always valid) addresses, zeroed afterwards: a guarded load costs a saved exec
+        // mask each, and all of them are in flight together
+        {
+            const int jc = jok ? j : 0, cc = cok ? c0 : 0;
+#pragma unroll
+            for (int it = 0; it < KCH; ++it)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int b = b_lo + 16 * it + 4 * l4 + ks, bc = min(b, n - 1);              // permuted k order
+                    av[it][ks] = d.dx2[(size_t)bc * H2 + jc];                                      // A[i = j][k = b]
+                    bv[it][ks] = *reinterpret_cast<const float4 *>(sv.h1 + (size_t)bc * H1 + cc);
+                }
+#pragma unroll
+            for (int it = 0; it < KCH; ++it)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int b = b_lo + 16 * it + 4 * l4 + ks;
+                    if (!(b < b_hi && jok)) av[it][ks] = 0.f;
+                    if (!(b < b_hi && cok)) bv[it][ks] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+        }
+        // the four elements' optimizer state: requested with the operands (the updates below also store through pointers that
+        // may alias a later load)
+        AdamElem el[4] = {};
+        if (A.on && own) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jr = jt * 16 + l4 * 4 + r;
+                if (jr < H2) el[r] = adam_load(A, 4, (size_t)jr * H1 + col);
+            }
+        }
+        WST(0);
+        fill_factors();
+        WST(1);
+#pragma unroll
+        for (int it = 0; it < KCH; ++it) {
+            float a[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int b = b0 + 4 * l4 + ks;                                          // permuted k order
-                av[ks] = (b < b_hi && jok) ? d.dx2[(size_t)b * H2 + j] * row_factor(RS, b) : 0.f;   // A[i = j][k = b]
-                bv[ks] = (b < b_hi && cok) ? *reinterpret_cast<const float4 *>(sv.h1 + (size_t)b * H1 + c0)
+                const int b = b_lo + 16 * it + 4 * l4 + ks;
+                a[ks] = ROWSCALE ? (b < b_hi ? av[it][ks] * row_factor(b) : 0.f) : av[it][ks];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv[it][ks].x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv[it][ks].y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv[it][ks].z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bv[it][ks].w, acc[3], 0, 0, 0);
+            }
+        }
+        for (int b0 = b_lo + 16 * KCH; b0 < b_hi; b0 += 16) {          // (batches beyond 256 rows: one k16 step at a time)
+            float a[4];
+            float4 bb[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int b = b0 + 4 * l4 + ks;
+                a[ks] = (b < b_hi && jok) ? d.dx2[(size_t)b * H2 + j] * row_factor(b) : 0.f;
+                bb[ks] = (b < b_hi && cok) ? *reinterpret_cast<const float4 *>(sv.h1 + (size_t)b * H1 + c0)
                                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks].x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks].y, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks].z, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks].w, acc[3], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bb[ks].x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bb[ks].y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bb[ks].z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bb[ks].w, acc[3], 0, 0, 0);
             }
         }
+        WST(2);
 #pragma unroll
         for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4 *>(&part[wave][t][lane * 4]) = acc[t];
-        __syncthreads();
+        float bc1, sqrt_bc2;
+        bias_corrections(bc1, sqrt_bc2);
+        WST(3);
+        lds_barrier();
+        WST(4);
         // wave w finishes output tile t = w: sum the four K-quarters in a fixed order
         const f32x4 p0 = *reinterpret_cast<const f32x4 *>(&part[0][wave][lane * 4]);
         const f32x4 p1 = *reinterpret_cast<const f32x4 *>(&part[1][wave][lane * 4]);
         const f32x4 p2 = *reinterpret_cast<const f32x4 *>(&part[2][wave][lane * 4]);
         const f32x4 p3 = *reinterpret_cast<const f32x4 *>(&part[3][wave][lane * 4]);
-        const int col = grp * 64 + 4 * l15 + wave;                       // tile t holds columns c0 + t
         float pnew[4] = {0.f, 0.f, 0.f, 0.f}, tnew[4] = {0.f, 0.f, 0.f, 0.f};      // updated parameter / target (0 = padding)
-        if (col < H1 && grp * 64 + 4 * l15 < H1) {
-            // the four elements' optimizer state first: the updates below store through pointers that may alias a later load
-            AdamElem el[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int jr = jt * 16 + l4 * 4 + r;
-                if (A.on && jr < H2) el[r] = adam_load(A, 4, (size_t)jr * H1 + col);
-            }
+        if (own) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int jr = jt * 16 + l4 * 4 + r;
@@ -1003,13 +1102,14 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
                 }
             }
         }
+        WST(5);
         if (A.on && (A.img_p || A.img_t)) {
             // The block's 16 x 64 patch of fc2 in the images the learn() kernels read instead of w2 (fragment order, see
             // IMG_FWD above): exactly two consecutive 1 KB fragments of each forward plane (rows = tile jt, k32 steps
             // 2 grp, 2 grp + 1) and half a fragment (512 B) of each of the group's four backward tiles.  Pieces are staged
             // in LDS in that order and leave as 16-byte stores; scattered 2-byte stores cost 10 us per launch.
             _Float16 (*stage)[1024] = reinterpret_cast<_Float16 (*)[1024]>(&part[0][0][0]);      // 6 x 2 KB of the 16 KB
-            __syncthreads();                                              // every wave has read its partial sums
+            lds_barrier();                                              // every wave has read its partial sums
             const int kq = 4 * l15 + wave;                                // column inside the group
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1020,7 +1120,7 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
                 const int b = wave * 256 + ((l4 >> 1) * 16 + l15) * 8 + (l4 & 1) * 4 + r;
                 stage[0][f] = ph; stage[1][f] = pm; stage[2][b] = ph; stage[3][b] = pm; stage[4][f] = th; stage[5][f] = tm;
             }
-            __syncthreads();
+            lds_barrier();
             const size_t fbase = (size_t)(jt * FW_STEPS + 2 * grp) * 512;
             const int fcount = grp < NG - 1 ? 128 : 64;                   // the last group has one k32 step (columns 384..415)
             for (int q = tid; q < 6 * 128; q += 256) {
@@ -1038,45 +1138,74 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
                 }
             }
         }
+        WST(6);
         STAMPB(13, 0);
 #ifdef TT_STAMPS
         __syncthreads(); if (threadIdx.x == 0) g_blk[blockIdx.x][1] = wall_clock64();
 #endif
+        WST(7);
     } else if (blk < NU2 + NU1) {
         const int jt = blk - NU2, j = jt * 16 + l15;
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        for (int b0 = b_lo; b0 < b_hi; b0 += 16) {
-            float av[4], b0v[4], b1v[4];
+        float av[KCH][4], b0v[KCH][4], b1v[KCH][4];
+#pragma unroll
+        for (int it = 0; it < KCH; ++it)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int b = b_lo + 16 * it + 4 * l4 + ks, bc = min(b, n - 1);
+                av[it][ks] = d.dx1[(size_t)bc * H1 + j];
+                b0v[it][ks] = obs[(size_t)bc * IN + l15];                                            // columns 0..15
+                b1v[it][ks] = obs[(size_t)bc * IN + (16 + l15 < IN ? 16 + l15 : 0)];                 // 16..22
+            }
+#pragma unroll
+        for (int it = 0; it < KCH; ++it)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int b = b_lo + 16 * it + 4 * l4 + ks;
+                if (!(b < b_hi)) { av[it][ks] = 0.f; b0v[it][ks] = 0.f; }
+                if (!(b < b_hi && 16 + l15 < IN)) b1v[it][ks] = 0.f;
+            }
+        const int col = wave * 16 + l15;
+        const bool own = wave < 2 && col < IN;
+        AdamElem el[4] = {};
+        if (A.on && own) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) el[r] = adam_load(A, 0, (size_t)(jt * 16 + l4 * 4 + r) * IN + col);
+        }
+        fill_factors();
+#pragma unroll
+        for (int it = 0; it < KCH; ++it) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int b = b_lo + 16 * it + 4 * l4 + ks;
+                const float a = ROWSCALE ? (b < b_hi ? av[it][ks] * row_factor(b) : 0.f) : av[it][ks];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0v[it][ks], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1v[it][ks], acc[1], 0, 0, 0);
+            }
+        }
+        for (int b0 = b_lo + 16 * KCH; b0 < b_hi; b0 += 16) {          // (batches beyond 256 rows)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int b = b0 + 4 * l4 + ks;
-                av[ks] = b < b_hi ? d.dx1[(size_t)b * H1 + j] * row_factor(RS, b) : 0.f;
-                b0v[ks] = b < b_hi ? obs[(size_t)b * IN + l15] : 0.f;                            // columns 0..15
-                b1v[ks] = (b < b_hi && 16 + l15 < IN) ? obs[(size_t)b * IN + 16 + l15] : 0.f;    // 16..22
-            }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], b0v[ks], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], b1v[ks], acc[1], 0, 0, 0);
+                const float a = b < b_hi ? d.dx1[(size_t)b * H1 + j] * row_factor(b) : 0.f;
+                const float x0 = b < b_hi ? obs[(size_t)b * IN + l15] : 0.f;
+                const float x1 = (b < b_hi && 16 + l15 < IN) ? obs[(size_t)b * IN + 16 + l15] : 0.f;
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x1, acc[1], 0, 0, 0);
             }
         }
         *reinterpret_cast<f32x4 *>(&part[wave][0][lane * 4]) = acc[0];
         *reinterpret_cast<f32x4 *>(&part[wave][1][lane * 4]) = acc[1];
-        __syncthreads();
-        if (wave < 2) {
-            const int col = wave * 16 + l15;
-            if (col < IN) {
-                AdamElem el[4];
+        float bc1, sqrt_bc2;
+        bias_corrections(bc1, sqrt_bc2);
+        lds_barrier();
+        if (own) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (A.on) el[r] = adam_load(A, 0, (size_t)(jt * 16 + l4 * 4 + r) * IN + col);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float g = ((part[0][wave][lane * 4 + r] + part[1][wave][lane * 4 + r]) + part[2][wave][lane * 4 + r]) +
-                                    part[3][wave][lane * 4 + r];
-                    G.w1[(size_t)(jt * 16 + l4 * 4 + r) * IN + col] = g;
-                    if (A.on) adam_finish(A, 0, (size_t)(jt * 16 + l4 * 4 + r) * IN + col, g, el[r], bc1, sqrt_bc2);
-                }
+            for (int r = 0; r < 4; ++r) {
+                const float g = ((part[0][wave][lane * 4 + r] + part[1][wave][lane * 4 + r]) + part[2][wave][lane * 4 + r]) +
+                                part[3][wave][lane * 4 + r];
+                G.w1[(size_t)(jt * 16 + l4 * 4 + r) * IN + col] = g;
+                if (A.on) adam_finish(A, 0, (size_t)(jt * 16 + l4 * 4 + r) * IN + col, g, el[r], bc1, sqrt_bc2);
             }
         }
         STAMPB(15, NU2);
@@ -1100,7 +1229,7 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
         const int c = cb * 64 + lane;
         const bool valid = cat >= 0 && c < base;
         // every quantity is sum_b A[b*sa + ca] (* B[b*sb + cb]); the operands are picked ONCE per workgroup so that the
-        // row loops below are straight-line: 16 (or 32) independent loads in flight, then one add chain in row order.
+        // row loops below are straight-line: the loads of 64 rows in flight at once, then one add chain in row order.
         // (A per-term switch on the quantity serialises the loads: one L2/HBM round trip per row.)
         const float *Ap = nullptr, *Bp = nullptr;
         int sa = 0, sb = 0, ca = 0, cbb = 0;
@@ -1117,41 +1246,59 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
             case 9: Ap = d.dz; sa = H2; ca = c; break;                                    // dba
             default: break;
         }
-        float acc = 0.f;
-        if (valid) {
-            const int rows = (n + 3) / 4, lo = wave * rows, hi = min(n, lo + rows);
-            const float *pa = Ap + ca, *pb = Bp ? Bp + cbb : nullptr;
-            int b = lo;
-            if (pb) {
-                for (; b + 16 <= hi; b += 16) {
-                    float t[16], u2[16], f[16];
+        // the quantity's tensor (tt_mlp_weights order: w1 b1 g1 be1 w2 b2 g2 be2 w3 b3 wa ba), its gradient row and optimizer
+        // state: ONE run-time index into the kernel-argument tables (a per-case choice of the pointers made the compiler keep
+        // all 40 of them live in scalar registers: > 1000 spill instructions)
+        const int tensor = cat < 0 ? 0 : (cat < 3 ? cat + 5 : (cat < 6 ? cat - 2 : cat + 2));
+        float *const outp = reinterpret_cast<float *const *>(&G)[tensor];
+        AdamPtrs ad{nullptr, nullptr, nullptr, nullptr};
+        if (A.on) ad = AdamPtrs{A.p[tensor], A.m[tensor], A.v[tensor], A.tgt[tensor]};
+        constexpr int RCH = 32;                    // rows in flight per wave: two rounds at 256 rows (these workgroups do little else)
+        const int rows = (n + 3) / 4, lo = wave * rows, hi = min(n, lo + rows);
+        // unconditional loads from clamped addresses (see the dW2 blocks); a quantity without a second operand reads its first
+        // one twice (same lines) and multiplies by 1
+        const bool has_b = Bp != nullptr;
+        const int cc = valid ? c : 0;
+        const float *pa = Ap + (sa == 1 ? 0 : cc), *pb = has_b ? Bp + (sb == 1 ? 0 : cc) : pa;
+        float t[RCH], u2[RCH];
+        // row strides in VECTOR registers: as scalars the compiler forms all 2 x 32 products u * stride up front and keeps
+        // them live in (then spilled) scalar registers
+        int sav = sa, sbv = has_b ? sb : sa;
+        asm volatile("" : "+v"(sav), "+v"(sbv));
+        auto load_rows = [&](const int b0) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) { t[u] = pa[(size_t)(b + u) * sa]; u2[u] = pb[(size_t)(b + u) * sb]; f[u] = row_factor(RS, b + u); }
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) acc += (t[u] * f[u]) * u2[u];
-                }
-                for (; b < hi; ++b) acc += (pa[(size_t)b * sa] * row_factor(RS, b)) * pb[(size_t)b * sb];
-            } else {
-                for (; b + 16 <= hi; b += 16) {
-                    float t[16], f[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) { t[u] = pa[(size_t)(b + u) * sa]; f[u] = row_factor(RS, b + u); }
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) acc += t[u] * f[u];
-                }
-                for (; b < hi; ++b) acc += pa[(size_t)b * sa] * row_factor(RS, b);
+            for (int u = 0; u < RCH; ++u) {
+                const int bc = min(b0 + u, n - 1);
+                t[u] = pa[bc * sav];
+                u2[u] = pb[bc * sbv];
             }
+#pragma unroll
+            for (int u = 0; u < RCH; ++u) {
+                if (!(valid && b0 + u < hi)) t[u] = 0.f;
+                if (!has_b) u2[u] = 1.f;
+            }
+        };
+        load_rows(lo);
+        AdamElem e0{};
+        if (A.on && wave == 0 && valid) e0 = adam_load(ad, (size_t)c);
+        fill_factors();
+        float acc = 0.f;
+        for (int b0 = lo; b0 < hi; b0 += RCH) {
+            if (b0 != lo) load_rows(b0);
+            // products rounded, then added in row order (what (dz * xh2).sum(0) does in the reference; written with the
+            // _rn forms so that the compiler contracts none of them into an fma: the sums then do not depend on its choices)
+#pragma unroll
+            for (int u = 0; u < RCH; ++u)
+                acc = __fadd_rn(acc, __fmul_rn(ROWSCALE ? __fmul_rn(t[u], row_factor(min(b0 + u, n - 1))) : t[u], u2[u]));
         }
         part[wave][0][lane] = acc;
-        __syncthreads();
+        float bc1, sqrt_bc2;
+        bias_corrections(bc1, sqrt_bc2);
+        lds_barrier();
         if (wave == 0 && valid) {
             const float total = ((part[0][0][lane] + part[1][0][lane]) + part[2][0][lane]) + part[3][0][lane];
-            float *const outs[NCAT] = {G.b2, G.g2, G.be2, G.b1, G.g1, G.be1, G.w3, G.b3, G.wa, G.ba};
-            outs[cat][c] = total;
-            if (A.on) {
-                const int tensor[NCAT] = {5, 6, 7, 1, 2, 3, 8, 9, 10, 11};
-                adam_apply(A, tensor[cat], (size_t)c, total, bc1, sqrt_bc2);
-            }
+            outp[c] = total;
+            if (A.on) adam_finish(A, ad, (size_t)c, total, e0, bc1, sqrt_bc2);
         }
         STAMPB(6, NU2 + NU1);
 #ifdef TT_STAMPS
@@ -1497,6 +1644,9 @@ int tt_mlp_fc2_image_pack(const tt_mlp_weights *w, tt_stream_t stream) {
 #ifdef TT_STAMPS
 int tt_debug_blocks(unsigned long long *out1024) {
     return hipMemcpyFromSymbol(out1024, HIP_SYMBOL(g_blk), sizeof(unsigned long long) * 1024) == hipSuccess ? 0 : -3;
+}
+int tt_debug_wst(unsigned long long *out32) {
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_wst), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -3;
 }
 int tt_debug_kblocks(unsigned long long *out6x1024) {
     return hipMemcpyFromSymbol(out6x1024, HIP_SYMBOL(g_kblk), sizeof(unsigned long long) * 6 * 1024) == hipSuccess ? 0 : -3;

@@ -189,17 +189,33 @@ __global__ __launch_bounds__(256) void k_pack_and_sample(const Weights W, const 
     if (b < R.batch) ring_sample_row(R, b, threadIdx.x & 63);
 }
 
+// LDS reads through laundered address-space-3 bases.  The ring + vectors span 152 KB and a ds_read's immediate offset reaches
+// 64 KB, so three byte bases (0, 64 KB, 128 KB; + this lane's 16 bytes) cover every fragment with an immediate; the bases pass
+// through an empty asm at the top of every tile so that the compiler can neither hoist the ~300 fragment addresses of a tile out
+// of the tile loop nor keep them live across it (the loop form spilled ~400 registers that way).
+using lds_b = const __attribute__((address_space(3))) unsigned char;
+using v4u = __attribute__((ext_vector_type(4))) unsigned;
+struct LdsBases {
+    lds_b *b0, *b1, *b2;
+};
+__device__ __forceinline__ uint4 lds_frag(const LdsBases &L, const int off) {      // off: compile-time byte offset (+ lane * 16)
+    lds_b *p = (off >> 16) == 0 ? L.b0 : ((off >> 16) == 1 ? L.b1 : L.b2);
+    const v4u t = *(const __attribute__((address_space(3))) v4u *)(p + (off & 0xFFFF));
+    return make_uint4(t[0], t[1], t[2], t[3]);
+}
+
+// One workgroup = 4 waves = 128 envs per TILE; a workgroup takes the tiles tile0 + blockIdx.x, + gridDim.x, ... < tile_end in
+// turn.  From the second tile on, the tile's observations, packed fc1 and the first two k16 steps of fc2 are requested before
+// the PREVIOUS tile's epilogue and land behind it; the per-neuron vectors stay in LDS.
 template <bool CRITIC>
-__global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int tile0, const float *__restrict__ obs,
+__global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int tile0, const int tile_end,
+                                                      const float *__restrict__ obs,
                                                       const float *__restrict__ action,
                                                       const unsigned char *__restrict__ ws,
                                                       const unsigned char *__restrict__ ws_alt, float *__restrict__ out,
                                                       const ActArgs act) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const uint4 *ring = reinterpret_cast<const uint4 *>(lds_raw);             // RING x one k16 step of packed fc2
-    const uint4 *w1_s = reinterpret_cast<const uint4 *>(lds_raw + W1_OFF);    // packed fc1 [2][13][2][64] (in ring slots 2..4)
     const float *p1_s = reinterpret_cast<const float *>(lds_raw + RING_BYTES);              // g1' | be1'       [2][416]
-    const float *p2_s = p1_s + 2 * H1P;                                       // b2 | g2 | be2 | w3 | wa | ba [6][320]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -211,302 +227,349 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
         const v4 t = *(const __attribute__((address_space(3))) v4 *)q;
         return make_float4(t[0], t[1], t[2], t[3]);
     };
-    lds_f *pv1 = (lds_f *)(p1_s + 4 * h);
-    asm volatile("" : "+v"(pv1));
-    lds_f *pv2 = pv1 + 2 * H1P;
-    // One 128-env tile per workgroup (a loop over tiles inside the kernel costs ~400 spilled registers: the compiler hoists
-    // the tile-invariant DMA addresses); a caller that wants CUs left free launches the tiles in several grids (tile0).
-    const int tile = tile0 + blockIdx.x;
+    lds_f *pv1_0 = (lds_f *)(p1_s + 4 * h);
+    LdsBases LB0;
+    LB0.b0 = (lds_b *)lds_raw + lane * 16;
+    LB0.b1 = LB0.b0 + 65536;
+    LB0.b2 = LB0.b0 + 131072;
     // ring addressing: the image of the running step's parity (the other one may be being written for the next step), and
     // the first workgroup leaves the running step's cursor where the env step reads it
     const bool odd = act.cursor && (*act.step_dev & 1);
     const unsigned char *wsl = (odd && ws_alt) ? ws_alt : ws;
-    if (act.cursor && tile == 0 && tid < 4) act.cursor[tid] = cursor_of(act)[tid];
-    const int row = tile * ROWS + wave * WROWS + r;                           // this lane's env (lanes r and r+32 share it)
+    if (act.cursor && tile0 == 0 && blockIdx.x == 0 && tid < 4) act.cursor[tid] = cursor_of(act)[tid];
+    const float *obs_base = resolve_obs(act, obs);
 
     // LDS is filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = one 1 KB piece per wave-instruction, no
     // staging registers).  The statements are inline asm, so hipcc neither counts them nor drains them at a barrier:
     // each wave retires its own pieces with an s_waitcnt vmcnt before the barrier that precedes their first read.
-    const unsigned lane_off = lane * 16;
-    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw;
-    auto dma_piece = [&](const unsigned char *src, const unsigned dst) {      // src, dst wave-uniform; + lane * 16 each
+    // A piece = global bytes [base + voff .. + 1 KB) -> LDS [lds_wave + dst_const .. + 1 KB).  The global side is ONE SGPR base
+    // (the image) plus a per-lane VGPR offset that carries everything else (lane * 16, the wave's share, the piece), the LDS side
+    // a per-wave SGPR plus a constant added INSIDE the asm: no scalar address arithmetic is left to the compiler, which forms
+    // 64-bit scalar adds on the vector ALU when SCC is live and then cannot feed them to an "s" operand.
+    const unsigned lds_base0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_raw;
+    auto dma_piece = [&](const unsigned char *base, const unsigned voff, const unsigned lds_wave, const unsigned dst_const)
+                         __attribute__((always_inline)) {
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(lane_off), "s"(src), "s"(dst) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_wave), "s"(dst_const) : "memory", "scc");
     };
-    const unsigned char *wsl_cur = wsl;
-    auto chunk_issue_piece = [&](const int s, const int i) {                  // piece i (0..4) of this wave's share of step s
-        dma_piece(wsl_cur + WS_W2 + (size_t)s * CHUNK_BYTES + wave * 5120 + i * 1024,
-                  lds_base + (s % RING) * CHUNK_BYTES + wave * 5120 + i * 1024);
+    const unsigned voff_w2 = lane * 16 + wave * 5120 + WS_W2;                              // this wave's 5 pieces of a k16 step
+    const unsigned voff_w1 = lane * 16 + wave * (W1_PIECES / 4) * 1024 + WS_W1;            // ... 13 pieces of packed fc1
+    const unsigned voff_vec = lane * 16 + wave * (VEC_PIECES / 4) * 1024 + WS_VEC;         // ... 3 pieces of the vectors
+    const unsigned ldsw_w2_0 = lds_base0 + wave * 5120, ldsw_w1_0 = lds_base0 + W1_OFF + wave * (W1_PIECES / 4) * 1024;
+    // this wave's share of packed fc1 (13 pieces) / of k16 step s of fc2 (5 pieces), from image `w`
+    auto issue_fc1 = [&](const unsigned char *w, const unsigned ldsw_w1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < W1_PIECES / 4; ++i) dma_piece(w, voff_w1 + i * 1024, ldsw_w1, i * 1024);
+    };
+    auto issue_step_piece = [&](const unsigned char *w, const unsigned ldsw_w2, const int s, const int i) __attribute__((always_inline)) {
+        dma_piece(w, voff_w2 + s * CHUNK_BYTES + i * 1024, ldsw_w2, (s % RING) * CHUNK_BYTES + i * 1024);
+    };
+    // unconditional loads from clamped (always valid) addresses, selected afterwards: 16 loads in flight at once
+    // instead of 16 exec-masked round trips
+    float xo[S1][8];                                                          // obs^T as the B operand: input 16 s + 8 h + j
+    auto load_obs = [&](const int tile) __attribute__((always_inline)) {
+        const int row = tile * ROWS + wave * WROWS + r;
+        const float *orow = obs_base + (size_t)(row < n ? row : n - 1) * IN;
+#pragma unroll
+        for (int s = 0; s < S1; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * s + 8 * h + j;
+                xo[s][j] = orow[k < IN ? k : IN - 1];
+            }
     };
 
     NSTAMP(0);
-    // ---- prologue: this lane's observation features first (ordinary loads: the compiler waits for them on its own
-    // count), then packed fc1 + the per-neuron vectors, then k16 steps 0 and 1 of fc2 by DMA
-    float xo[S1][8];                                                          // obs^T as the B operand: input 16 s + 8 h + j
-    // unconditional loads from clamped (always valid) addresses, selected afterwards: 16 loads in flight at once
-    // instead of 16 exec-masked round trips
-    const float *orow = resolve_obs(act, obs) + (size_t)(row < n ? row : n - 1) * IN;
-#pragma unroll
-    for (int s = 0; s < S1; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 16 * s + 8 * h + j;
-            xo[s][j] = orow[k < IN ? k : IN - 1];
-        }
-#pragma unroll
-    for (int i = 0; i < W1_PIECES / 4; ++i)
-        dma_piece(wsl + WS_W1 + (wave * (W1_PIECES / 4) + i) * 1024, lds_base + W1_OFF + (wave * (W1_PIECES / 4) + i) * 1024);
+    // ---- prologue of the FIRST tile: this lane's observation features first (ordinary loads: the compiler waits for them on
+    // its own count), then packed fc1 + the per-neuron vectors, then k16 steps 0 and 1 of fc2 by DMA
+    int tile = tile0 + (int)blockIdx.x;
+    if (tile >= tile_end) return;
+    load_obs(tile);
+    issue_fc1(wsl, ldsw_w1_0);
 #pragma unroll
     for (int i = 0; i < VEC_PIECES / 4; ++i)
-        dma_piece(wsl + WS_VEC + (wave * (VEC_PIECES / 4) + i) * 1024,
-                  lds_base + RING_BYTES + (wave * (VEC_PIECES / 4) + i) * 1024);
+        dma_piece(wsl, voff_vec + i * 1024, lds_base0 + RING_BYTES + wave * (VEC_PIECES / 4) * 1024, i * 1024);
 #pragma unroll
-    for (int i = 0; i < 10; ++i) chunk_issue_piece(i / 5, i % 5);
-#pragma unroll
-    for (int s = 0; s < S1; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 16 * s + 8 * h + j;
-            xo[s][j] = k < IN ? (row < n ? xo[s][j] : 0.f) : (k == IN ? 1.f : 0.f);
-        }
-    uint4 xb[S1][2];                                                          // the observation's h and m pieces
-#pragma unroll
-    for (int s = 0; s < S1; ++s) {
-        uint32_t ph[4], pm[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) split2(xo[s][2 * p] * SX, xo[s][2 * p + 1] * SX, ph[p], pm[p]);
-        xb[s][0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-        xb[s][1] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
-    }
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                         // fc1 + vectors landed; fc2 steps 0, 1 may still fly
-    __builtin_amdgcn_s_barrier();
-    NSTAMP(1);
+    for (int i = 0; i < 10; ++i) issue_step_piece(wsl, ldsw_w2_0, i / 5, i % 5);
+    bool first = true;
 
-    // ---- layer 1: acc1[t][v] = SX*SW * (pre-activation + bias) of neuron 32t + 8(v>>2) + 4h + (v&3), env `row`
-    f32x16 acc1[T1];
+#pragma unroll 1
+    for (;;) {
+        // tile-invariant addresses, opaque per tile (see LdsBases)
+        const unsigned char *wsl_cur = wsl;
+        unsigned ldsw_w2 = ldsw_w2_0, ldsw_w1 = ldsw_w1_0;
+        LdsBases LB = LB0;
+        lds_f *pv1 = pv1_0;
+        asm volatile("" : "+s"(wsl_cur), "+s"(ldsw_w2), "+s"(ldsw_w1), "+v"(LB.b0), "+v"(LB.b1), "+v"(LB.b2), "+v"(pv1));
+        lds_f *pv2 = pv1 + 2 * H1P;
+        const int row = tile * ROWS + wave * WROWS + r;                       // this lane's env (lanes r and r+32 share it)
 #pragma unroll
-    for (int t = 0; t < T1; ++t) {
+        for (int s = 0; s < S1; ++s)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc1[t][v] = 0.f;
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * s + 8 * h + j;
+                xo[s][j] = k < IN ? (row < n ? xo[s][j] : 0.f) : (k == IN ? 1.f : 0.f);
+            }
+        uint4 xb[S1][2];                                                      // the observation's h and m pieces
 #pragma unroll
         for (int s = 0; s < S1; ++s) {
-            const uint4 ah = w1_s[((s * T1 + t) * 2) * 64 + lane], am = w1_s[((s * T1 + t) * 2 + 1) * 64 + lane];
-            acc1[t] = mfma_f16(am, xb[s][0], acc1[t]);                        // small terms first
-            acc1[t] = mfma_f16(ah, xb[s][1], acc1[t]);
-            acc1[t] = mfma_f16(ah, xb[s][0], acc1[t]);
+            uint32_t ph[4], pm[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) split2(xo[s][2 * p] * SX, xo[s][2 * p + 1] * SX, ph[p], pm[p]);
+            xb[s][0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+            xb[s][1] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
         }
-    }
-    NSTAMP(2);
-    // every wave is done with packed fc1: its slots now take k16 steps 2..5 of fc2 (they land during LayerNorm 1)
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i = 10; i < 5 * (AHEAD + 1); ++i) chunk_issue_piece(i / 5, i % 5);
-    uint32_t hb[STEPS_FULL][4], mb[STEPS_FULL][4];
-    // LayerNorm(400) (biased variance, eps 1e-5) on the SCALED pre-activations: mean and deviations scale with them,
-    // 1/sigma absorbs the scale; then gamma*SX, beta*SX and ReLU give the layer-2 operand already scaled by SX.
-    // Tile 12 holds neurons 384..399 in v < 8.
-    {
-        f32x2 sp = pk(0.f, 0.f);
-#pragma unroll
-        for (int t = 0; t < T1; ++t)
-#pragma unroll
-            for (int v = 0; v < (t == T1 - 1 ? 8 : 16); v += 4)
-                sp += pk(acc1[t][v], acc1[t][v + 1]) + pk(acc1[t][v + 2], acc1[t][v + 3]);
-        const float s = sp[0] + sp[1];
-        const float mean = (s + __shfl_xor(s, 32)) * (1.f / H1);
-        const f32x2 nmean = pk(-mean, -mean);
-        f32x2 ssp = pk(0.f, 0.f);
-#pragma unroll
-        for (int t = 0; t < T1; ++t)
-#pragma unroll
-            for (int v = 0; v < (t == T1 - 1 ? 8 : 16); v += 2) {
-                const f32x2 d = pk(acc1[t][v], acc1[t][v + 1]) + nmean;
-                acc1[t][v] = d[0]; acc1[t][v + 1] = d[1];
-                ssp = pk_fma(d, d, ssp);
-            }
-        const float ss = ssp[0] + ssp[1];
-        const float var = (ss + __shfl_xor(ss, 32)) * (1.f / H1) * (UNSCALE * UNSCALE);
-        const float rstd = rsqrtf(var + 1e-5f) * UNSCALE;
-        const f32x2 rstdp = pk(rstd, rstd);
-        // gamma*SX, beta*SX, ReLU, then straight into the two f16 pieces layer 2 multiplies with: hb[s] / mb[s] are the
-        // B fragments (h, m planes) of k16 step s -- element j of lane half h is neuron 16 s + 8 (j >> 2) + 4 h + (j & 3),
-        // i.e. registers 8 (s & 1) .. + 7 of tile s >> 1, the order the packed fc2 fragments are laid out in
-        // The per-neuron vectors come from LDS a whole tile AHEAD of their use (8 ds_read_b128, pinned above the tile's
-        // arithmetic): a lone wave hides no latency, and read-then-use cost one exposed LDS round trip per group of four.
-        float4 gq[2][4], bq[2][4];
-        auto ld1 = [&](const int t, float4 (&g)[4], float4 (&be)[4]) {
-#pragma unroll
-            for (int i = 0; i < (t == T1 - 1 ? 2 : 4); ++i) {
-                g[i] = lds4(pv1 + 32 * t + 8 * i);
-                be[i] = lds4(pv1 + H1P + 32 * t + 8 * i);
-            }
-        };
-        ld1(0, gq[0], bq[0]);
+        // first tile: fc1 + vectors landed, fc2 steps 0, 1 may still fly.  Later tiles: everything of this tile was requested
+        // before the previous tile's epilogue; that epilogue's stores are among the outstanding operations and stores and
+        // loads retire in no fixed order, so nothing short of 0 tells that the DMA pieces have landed
+        if (first) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (first) NSTAMP(1);
+
+        // ---- layer 1: acc1[t][v] = SX*SW * (pre-activation + bias) of neuron 32t + 8(v>>2) + 4h + (v&3), env `row`
+        f32x16 acc1[T1];
 #pragma unroll
         for (int t = 0; t < T1; ++t) {
-            if (t + 1 < T1) ld1(t + 1, gq[(t + 1) & 1], bq[(t + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < (t == T1 - 1 ? 2 : 4); ++i) {
-                const float4 g = gq[t & 1][i], be = bq[t & 1][i];
-                const f32x2 ya = pk_fma(pk(acc1[t][4 * i], acc1[t][4 * i + 1]) * rstdp, pk(g.x, g.y), pk(be.x, be.y));
-                const f32x2 yb = pk_fma(pk(acc1[t][4 * i + 2], acc1[t][4 * i + 3]) * rstdp, pk(g.z, g.w), pk(be.z, be.w));
-                const float y0 = fmaxf(ya[0], 0.f), y1 = fmaxf(ya[1], 0.f), y2 = fmaxf(yb[0], 0.f), y3 = fmaxf(yb[1], 0.f);
-                const int st = 2 * t + (i >> 1), e = 2 * (i & 1);             // k16 step, first of its two packed registers
-                split2(y0, y1, hb[st][e], mb[st][e]);
-                split2(y2, y3, hb[st][e + 1], mb[st][e + 1]);
+            for (int v = 0; v < 16; ++v) acc1[t][v] = 0.f;
+#pragma unroll
+            for (int s = 0; s < S1; ++s) {
+                const uint4 ah = lds_frag(LB, W1_OFF + ((s * T1 + t) * 2) * 1024), am = lds_frag(LB, W1_OFF + ((s * T1 + t) * 2 + 1) * 1024);
+                acc1[t] = mfma_f16(am, xb[s][0], acc1[t]);                    // small terms first
+                acc1[t] = mfma_f16(ah, xb[s][1], acc1[t]);
+                acc1[t] = mfma_f16(ah, xb[s][0], acc1[t]);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
-    }
-
-    NSTAMP(3);
-    // ---- layer 2: 25 k16 steps x 10 neuron tiles x 3 f16 MFMAs; the h1 registers are the B operand
-    f32x16 acc2[T2];
+        if (first) NSTAMP(2);
+        // every wave is done with packed fc1: its slots now take k16 steps 2..5 of fc2 (they land during LayerNorm 1)
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int u = 0; u < T2; ++u)
+        for (int i = 10; i < 5 * (AHEAD + 1); ++i) issue_step_piece(wsl_cur, ldsw_w2, i / 5, i % 5);
+        uint32_t hb[STEPS_FULL][4], mb[STEPS_FULL][4];
+        // LayerNorm(400) (biased variance, eps 1e-5) on the SCALED pre-activations: mean and deviations scale with them,
+        // 1/sigma absorbs the scale; then gamma*SX, beta*SX and ReLU give the layer-2 operand already scaled by SX.
+        // Tile 12 holds neurons 384..399 in v < 8.
+        {
+            f32x2 sp = pk(0.f, 0.f);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc2[u][v] = 0.f;
-    // Hand-pipelined issue order, pinned with sched_barrier(0) between every pair of instruction groups: each of the
-    // three MFMAs of a tile is followed by one small job that issues while the matrix pipe is busy (an MFMA holds the
-    // wave's issue port for 8 of its 32 cycles) -- the two fragment reads of the tile two ahead, and in tiles 5..9 one
-    // LDS-DMA piece of step s + 6.  No vector arithmetic is left in the loop: the B operand was split once, in LayerNorm 1.  One barrier per step, in
-    // the middle (before tile 5): it publishes step s + 1 (every wave has waited for its own pieces of it with a COUNTED
-    // vmcnt that leaves the four younger steps in flight) and tells that every wave is past step s - 1, whose slot the
-    // DMA of step s + 6 overwrites.  Fragments are read TWO tiles ahead
-    // (tiles 0, 1 of step s + 1 during tiles 8, 9 of step s, after that barrier), so a read has six MFMAs to land.
-#define SB __builtin_amdgcn_sched_barrier(0)
-    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");      // steps 0 and 1 (this wave's pieces); 2..5 may still fly
-    __builtin_amdgcn_s_barrier();
-    // A fragments (h, m) of three consecutive tiles: the current one, the next, and the one being read (two ahead);
-    // rotated by renaming at the end of every tile (the loops are fully unrolled: no moves)
-    uint4 c0h = ring[lane], c0m = ring[64 + lane], c1h = ring[128 + lane], c1m = ring[192 + lane], c2h = c0h, c2m = c0m;
-    SB;
+            for (int t = 0; t < T1; ++t)
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-        const uint4 vh = make_uint4(hb[s][0], hb[s][1], hb[s][2], hb[s][3]), vm = make_uint4(mb[s][0], mb[s][1], mb[s][2], mb[s][3]);
-        const uint4 *slot = ring + (s % RING) * CHUNK_U4 + lane;
-        const uint4 *nslot = ring + ((s + 1) % RING) * CHUNK_U4 + lane;
+                for (int v = 0; v < (t == T1 - 1 ? 8 : 16); v += 4)
+                    sp += pk(acc1[t][v], acc1[t][v + 1]) + pk(acc1[t][v + 2], acc1[t][v + 3]);
+            const float s = sp[0] + sp[1];
+            const float mean = (s + __shfl_xor(s, 32)) * (1.f / H1);
+            const f32x2 nmean = pk(-mean, -mean);
+            f32x2 ssp = pk(0.f, 0.f);
 #pragma unroll
-        for (int u = 0; u < T2; ++u) {
-            if (u == T2 / 2) {
-                // step s + 1 must have landed; the steps issued after it (up to four) may still be in flight
-                switch (STEPS - 2 - s < 4 ? STEPS - 2 - s : 4) {
-                    case 4: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-                    case 3: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-                    case 2: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-                    case 1: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            for (int t = 0; t < T1; ++t)
+#pragma unroll
+                for (int v = 0; v < (t == T1 - 1 ? 8 : 16); v += 2) {
+                    const f32x2 d = pk(acc1[t][v], acc1[t][v + 1]) + nmean;
+                    acc1[t][v] = d[0]; acc1[t][v + 1] = d[1];
+                    ssp = pk_fma(d, d, ssp);
                 }
+            const float ss = ssp[0] + ssp[1];
+            const float var = (ss + __shfl_xor(ss, 32)) * (1.f / H1) * (UNSCALE * UNSCALE);
+            const float rstd = rsqrtf(var + 1e-5f) * UNSCALE;
+            const f32x2 rstdp = pk(rstd, rstd);
+            // gamma*SX, beta*SX, ReLU, then straight into the two f16 pieces layer 2 multiplies with: hb[s] / mb[s] are the
+            // B fragments (h, m planes) of k16 step s -- element j of lane half h is neuron 16 s + 8 (j >> 2) + 4 h + (j & 3),
+            // i.e. registers 8 (s & 1) .. + 7 of tile s >> 1, the order the packed fc2 fragments are laid out in
+            // The per-neuron vectors come from LDS a whole tile AHEAD of their use (8 ds_read_b128, pinned above the tile's
+            // arithmetic): a lone wave hides no latency, and read-then-use cost one exposed LDS round trip per group of four.
+            float4 gq[2][4], bq[2][4];
+            auto ld1 = [&](const int t, float4 (&g)[4], float4 (&be)[4]) {
+#pragma unroll
+                for (int i = 0; i < (t == T1 - 1 ? 2 : 4); ++i) {
+                    g[i] = lds4(pv1 + 32 * t + 8 * i);
+                    be[i] = lds4(pv1 + H1P + 32 * t + 8 * i);
+                }
+            };
+            ld1(0, gq[0], bq[0]);
+#pragma unroll
+            for (int t = 0; t < T1; ++t) {
+                if (t + 1 < T1) ld1(t + 1, gq[(t + 1) & 1], bq[(t + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < (t == T1 - 1 ? 2 : 4); ++i) {
+                    const float4 g = gq[t & 1][i], be = bq[t & 1][i];
+                    const f32x2 ya = pk_fma(pk(acc1[t][4 * i], acc1[t][4 * i + 1]) * rstdp, pk(g.x, g.y), pk(be.x, be.y));
+                    const f32x2 yb = pk_fma(pk(acc1[t][4 * i + 2], acc1[t][4 * i + 3]) * rstdp, pk(g.z, g.w), pk(be.z, be.w));
+                    const float y0 = fmaxf(ya[0], 0.f), y1 = fmaxf(ya[1], 0.f), y2 = fmaxf(yb[0], 0.f), y3 = fmaxf(yb[1], 0.f);
+                    const int st = 2 * t + (i >> 1), e = 2 * (i & 1);         // k16 step, first of its two packed registers
+                    split2(y0, y1, hb[st][e], mb[st][e]);
+                    split2(y2, y3, hb[st][e + 1], mb[st][e + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        if (first) NSTAMP(3);
+        // ---- layer 2: 25 k16 steps x 10 neuron tiles x 3 f16 MFMAs; the h1 registers are the B operand
+        f32x16 acc2[T2];
+#pragma unroll
+        for (int u = 0; u < T2; ++u)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc2[u][v] = 0.f;
+        // Hand-pipelined issue order, pinned with sched_barrier(0) between every pair of instruction groups: each of the
+        // three MFMAs of a tile is followed by one small job that issues while the matrix pipe is busy (an MFMA holds the
+        // wave's issue port for 8 of its 32 cycles) -- the two fragment reads of the tile two ahead, and in tiles 5..9 one
+        // LDS-DMA piece of step s + 6.  No vector arithmetic is left in the loop: the B operand was split once, in LayerNorm 1.
+        // One barrier per step, in the middle (before tile 5): it publishes step s + 1 (every wave has waited for its own
+        // pieces of it with a COUNTED vmcnt that leaves the four younger steps in flight) and tells that every wave is past
+        // step s - 1, whose slot the DMA of step s + 6 overwrites.  Fragments are read TWO tiles ahead
+        // (tiles 0, 1 of step s + 1 during tiles 8, 9 of step s, after that barrier), so a read has six MFMAs to land.
+#define SB __builtin_amdgcn_sched_barrier(0)
+        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");      // steps 0 and 1 (this wave's pieces); 2..5 may still fly
+        __builtin_amdgcn_s_barrier();
+        // A fragments (h, m) of three consecutive tiles: the current one, the next, and the one being read (two ahead);
+        // rotated by renaming at the end of every tile (the loops are fully unrolled: no moves)
+        uint4 c0h = lds_frag(LB, 0), c0m = lds_frag(LB, 1024), c1h = lds_frag(LB, 2048), c1m = lds_frag(LB, 3072), c2h = c0h, c2m = c0m;
+        SB;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const uint4 vh = make_uint4(hb[s][0], hb[s][1], hb[s][2], hb[s][3]), vm = make_uint4(mb[s][0], mb[s][1], mb[s][2], mb[s][3]);
+            const int slot = (s % RING) * CHUNK_BYTES, nslot = ((s + 1) % RING) * CHUNK_BYTES;
+            // (per step, so that the step's five DMA addresses are formed here and not all 125 at the top of the tile)
+            const unsigned char *wsl_s = wsl_cur;
+            unsigned lds_s = ldsw_w2;
+            asm volatile("" : "+s"(wsl_s), "+s"(lds_s));
+#pragma unroll
+            for (int u = 0; u < T2; ++u) {
+                if (u == T2 / 2) {
+                    // step s + 1 must have landed; the steps issued after it (up to four) may still be in flight
+                    switch (STEPS - 2 - s < 4 ? STEPS - 2 - s : 4) {
+                        case 4: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+                        case 3: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+                        case 2: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                        case 1: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    }
 #ifndef TT_DBG_NOBAR
-                __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_s_barrier();
+#endif
+                    SB;
+                }
+                const bool more = u + 2 < T2 || s + 1 < STEPS;                // is there a tile two ahead to prefetch
+                const int nx = u + 2 < T2 ? slot + (u + 2) * 2048 : nslot + (u + 2 - T2) * 2048;
+                acc2[u] = mfma_f16(c0h, vm, acc2[u]); SB;      // small terms first
+                if (more) c2h = lds_frag(LB, nx);
+                SB;
+                acc2[u] = mfma_f16(c0m, vh, acc2[u]); SB;
+                if (more) c2m = lds_frag(LB, nx + 1024);
+                SB;
+                acc2[u] = mfma_f16(c0h, vh, acc2[u]); SB;
+#ifndef TT_DBG_NODMA
+                if (u >= 5 && s + RING - 1 < STEPS) issue_step_piece(wsl_s, lds_s, s + RING - 1, u - 5);
 #endif
                 SB;
+                c0h = c1h; c0m = c1m; c1h = c2h; c1m = c2m;
             }
-            const bool more = u + 2 < T2 || s + 1 < STEPS;                    // is there a tile two ahead to prefetch
-            const uint4 *nx = u + 2 < T2 ? slot + (u + 2) * 2 * 64 : nslot + (u + 2 - T2) * 2 * 64;
-            acc2[u] = mfma_f16(c0h, vm, acc2[u]); SB;      // small terms first
-            if (more) c2h = nx[0];
-            SB;
-            acc2[u] = mfma_f16(c0m, vh, acc2[u]); SB;
-            if (more) c2m = nx[64];
-            SB;
-            acc2[u] = mfma_f16(c0h, vh, acc2[u]); SB;
-#ifndef TT_DBG_NODMA
-            if (u >= 5 && s + RING - 1 < STEPS) chunk_issue_piece(s + RING - 1, u - 5);
-#endif
-            SB;
-            c0h = c1h; c0m = c1m; c1h = c2h; c1m = c2m;
         }
-    }
 #undef SB
 
-    NSTAMP(4);
-    // ---- epilogue: scale back + bias, LayerNorm(300), (critic: + action_value(a)), ReLU, head; acc2[u][v] is neuron
-    // 32u + 8(v>>2) + 4h + (v&3); 300 = 9*32 + 12, so groups of four are all real or all padding
-    // (the per-neuron vectors are read from LDS one tile ahead of their use, as in LayerNorm 1)
-    f32x2 s2p = pk(0.f, 0.f);
-    {
-        float4 bq[2][4];
-        auto ldb = [&](const int u, float4 (&b)[4]) {
+        if (first) NSTAMP(4);
+        // ---- the next tile of this workgroup: its observations, packed fc1 and fc2 steps 0, 1 are requested NOW (every wave is
+        // past its last fragment read: the ring is free) and land behind the epilogue below
+        const int next = tile + (int)gridDim.x;
+        const bool more_tiles = next < tile_end;
+        if (more_tiles) {
+            __builtin_amdgcn_s_barrier();
+            load_obs(next);
+            issue_fc1(wsl_cur, ldsw_w1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) b[i] = lds4(pv2 + 32 * u + 8 * i);   // zero beyond 300
-        };
-        ldb(0, bq[0]);
-#pragma unroll
-        for (int u = 0; u < T2; ++u) {
-            if (u + 1 < T2) ldb(u + 1, bq[(u + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 b = bq[u & 1][i];
-                const f32x2 xa = pk_fma(pk(acc2[u][4 * i], acc2[u][4 * i + 1]), pk(UNSCALE, UNSCALE), pk(b.x, b.y));
-                const f32x2 xb2 = pk_fma(pk(acc2[u][4 * i + 2], acc2[u][4 * i + 3]), pk(UNSCALE, UNSCALE), pk(b.z, b.w));
-                acc2[u][4 * i] = xa[0]; acc2[u][4 * i + 1] = xa[1]; acc2[u][4 * i + 2] = xb2[0]; acc2[u][4 * i + 3] = xb2[1];
-                s2p += xa + xb2;
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 10; ++i) issue_step_piece(wsl_cur, ldsw_w2, i / 5, i % 5);
         }
-    }
-    const float s2 = s2p[0] + s2p[1];
-    const float mean2 = (s2 + __shfl_xor(s2, 32)) * (1.f / H2);
-    const f32x2 nmean2 = pk(-mean2, -mean2);
-    // deviations in place (the last pass needs nothing else of the pre-activations); padding groups do not count
-    f32x2 ss2p = pk(0.f, 0.f);
+        // ---- epilogue: scale back + bias, LayerNorm(300), (critic: + action_value(a)), ReLU, head; acc2[u][v] is neuron
+        // 32u + 8(v>>2) + 4h + (v&3); 300 = 9*32 + 12, so groups of four are all real or all padding
+        // (the per-neuron vectors are read from LDS one tile ahead of their use, as in LayerNorm 1)
+        f32x2 s2p = pk(0.f, 0.f);
+        {
+            float4 bq[2][4];
+            auto ldb = [&](const int u, float4 (&b)[4]) {
 #pragma unroll
-    for (int u = 0; u < T2; ++u)
+                for (int i = 0; i < 4; ++i) b[i] = lds4(pv2 + 32 * u + 8 * i);   // zero beyond 300
+            };
+            ldb(0, bq[0]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool real = 32 * u + 8 * i + 4 * h < H2;
-            const f32x2 keep = real ? pk(1.f, 1.f) : pk(0.f, 0.f);
+            for (int u = 0; u < T2; ++u) {
+                if (u + 1 < T2) ldb(u + 1, bq[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                const f32x2 d = pk(acc2[u][4 * i + j], acc2[u][4 * i + j + 1]) + nmean2;
-                acc2[u][4 * i + j] = d[0]; acc2[u][4 * i + j + 1] = d[1];
-                const f32x2 dk = (32 * u + 8 * i + 4 < H2) ? d : d * keep;      // only the last tiles can hold padding
-                ss2p = pk_fma(dk, dk, ss2p);
-            }
-        }
-    const float ss2 = ss2p[0] + ss2p[1];
-    const float rstd2 = rsqrtf((ss2 + __shfl_xor(ss2, 32)) * (1.f / H2) + 1e-5f);
-    const f32x2 rstd2p = pk(rstd2, rstd2);
-    const float av = (CRITIC && row < n) ? action[row] : 0.f;
-    f32x2 dotp = pk(0.f, 0.f);
-    {
-        constexpr int NV = CRITIC ? 5 : 3;                  // gamma2, beta2, w3 (, wa, ba)
-        float4 vq[2][4][NV];
-        auto ldv = [&](const int u, float4 (&v)[4][NV]) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int q = 0; q < NV; ++q) v[i][q] = lds4(pv2 + (q + 1) * H2P + 32 * u + 8 * i);
-        };
-        ldv(0, vq[0]);
-#pragma unroll
-        for (int u = 0; u < T2; ++u) {
-            if (u + 1 < T2) ldv(u + 1, vq[(u + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 g = vq[u & 1][i][0], be = vq[u & 1][i][1], w3 = vq[u & 1][i][2];
-                f32x2 ya = pk_fma(pk(acc2[u][4 * i], acc2[u][4 * i + 1]) * rstd2p, pk(g.x, g.y), pk(be.x, be.y));
-                f32x2 yb = pk_fma(pk(acc2[u][4 * i + 2], acc2[u][4 * i + 3]) * rstd2p, pk(g.z, g.w), pk(be.z, be.w));
-                if (CRITIC) {
-                    const float4 wa = vq[u & 1][i][NV - 2], ba = vq[u & 1][i][NV - 1];
-                    ya += pk_fma(pk(av, av), pk(wa.x, wa.y), pk(ba.x, ba.y));
-                    yb += pk_fma(pk(av, av), pk(wa.z, wa.w), pk(ba.z, ba.w));
+                for (int i = 0; i < 4; ++i) {
+                    const float4 b = bq[u & 1][i];
+                    const f32x2 xa = pk_fma(pk(acc2[u][4 * i], acc2[u][4 * i + 1]), pk(UNSCALE, UNSCALE), pk(b.x, b.y));
+                    const f32x2 xb2 = pk_fma(pk(acc2[u][4 * i + 2], acc2[u][4 * i + 3]), pk(UNSCALE, UNSCALE), pk(b.z, b.w));
+                    acc2[u][4 * i] = xa[0]; acc2[u][4 * i + 1] = xa[1]; acc2[u][4 * i + 2] = xb2[0]; acc2[u][4 * i + 3] = xb2[1];
+                    s2p += xa + xb2;
                 }
-                dotp = pk_fma(pk(fmaxf(ya[0], 0.f), fmaxf(ya[1], 0.f)), pk(w3.x, w3.y), dotp);      // w3 = 0 on padding
-                dotp = pk_fma(pk(fmaxf(yb[0], 0.f), fmaxf(yb[1], 0.f)), pk(w3.z, w3.w), dotp);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
+        const float s2 = s2p[0] + s2p[1];
+        const float mean2 = (s2 + __shfl_xor(s2, 32)) * (1.f / H2);
+        const f32x2 nmean2 = pk(-mean2, -mean2);
+        // deviations in place (the last pass needs nothing else of the pre-activations); padding groups do not count
+        f32x2 ss2p = pk(0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < T2; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool real = 32 * u + 8 * i + 4 * h < H2;
+                const f32x2 keep = real ? pk(1.f, 1.f) : pk(0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const f32x2 d = pk(acc2[u][4 * i + j], acc2[u][4 * i + j + 1]) + nmean2;
+                    acc2[u][4 * i + j] = d[0]; acc2[u][4 * i + j + 1] = d[1];
+                    const f32x2 dk = (32 * u + 8 * i + 4 < H2) ? d : d * keep;      // only the last tiles can hold padding
+                    ss2p = pk_fma(dk, dk, ss2p);
+                }
+            }
+        const float ss2 = ss2p[0] + ss2p[1];
+        const float rstd2 = rsqrtf((ss2 + __shfl_xor(ss2, 32)) * (1.f / H2) + 1e-5f);
+        const f32x2 rstd2p = pk(rstd2, rstd2);
+        const float av = (CRITIC && row < n) ? action[row] : 0.f;
+        f32x2 dotp = pk(0.f, 0.f);
+        {
+            constexpr int NV = CRITIC ? 5 : 3;                  // gamma2, beta2, w3 (, wa, ba)
+            float4 vq[2][4][NV];
+            auto ldv = [&](const int u, float4 (&v)[4][NV]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) v[i][q] = lds4(pv2 + (q + 1) * H2P + 32 * u + 8 * i);
+            };
+            ldv(0, vq[0]);
+#pragma unroll
+            for (int u = 0; u < T2; ++u) {
+                if (u + 1 < T2) ldv(u + 1, vq[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 g = vq[u & 1][i][0], be = vq[u & 1][i][1], w3 = vq[u & 1][i][2];
+                    f32x2 ya = pk_fma(pk(acc2[u][4 * i], acc2[u][4 * i + 1]) * rstd2p, pk(g.x, g.y), pk(be.x, be.y));
+                    f32x2 yb = pk_fma(pk(acc2[u][4 * i + 2], acc2[u][4 * i + 3]) * rstd2p, pk(g.z, g.w), pk(be.z, be.w));
+                    if (CRITIC) {
+                        const float4 wa = vq[u & 1][i][NV - 2], ba = vq[u & 1][i][NV - 1];
+                        ya += pk_fma(pk(av, av), pk(wa.x, wa.y), pk(ba.x, ba.y));
+                        yb += pk_fma(pk(av, av), pk(wa.z, wa.w), pk(ba.z, ba.w));
+                    }
+                    dotp = pk_fma(pk(fmaxf(ya[0], 0.f), fmaxf(ya[1], 0.f)), pk(w3.x, w3.y), dotp);      // w3 = 0 on padding
+                    dotp = pk_fma(pk(fmaxf(yb[0], 0.f), fmaxf(yb[1], 0.f)), pk(w3.z, w3.w), dotp);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const float dot = dotp[0] + dotp[1];
+        const float v = dot + __shfl_xor(dot, 32) + lds4(pv1 - 4 * h + VEC_FLOATS).x;
+        if (h == 0 && row < n) finish_row<CRITIC>(row, v, out, act);
+        if (first) NSTAMP(5);
+        if (!more_tiles) break;
+        tile = next;
+        first = false;
     }
-    const float dot = dotp[0] + dotp[1];
-    const float v = dot + __shfl_xor(dot, 32) + p1_s[VEC_FLOATS];
-    if (h == 0 && row < n) finish_row<CRITIC>(row, v, out, act);
-    NSTAMP(5);
 }
 
 }  // namespace
@@ -542,35 +605,41 @@ template <bool CRITIC>
 static int launch_split(int n, const float *obs, const float *action, const tt_mlp_weights *w, float *out,
                         const ActArgs &act, hipStream_t stream) {
     static bool attr[64] = {};      // per device: a function attribute set on one device says nothing about another
+    static int cus[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return TT_EHIP;
     if (!attr[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp_split<CRITIC>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return TT_EHIP;
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        cus[dev] = c;
         attr[dev] = true;
     }
-    // one workgroup per CU is resident (LDS).  max_workgroups > 0: the tiles go out in consecutive grids of at most that
-    // many workgroups, so that never more than that many CUs are busy with this forward (the rest stay free for launches on
-    // other streams); 0: one grid, the hardware takes the tiles in rounds
+    // One workgroup per CU is resident (LDS), and a workgroup takes its tiles in turn (tile, tile + grid, ...).
+    // max_workgroups > 0: never more than that many CUs are busy with this forward (the rest stay free for launches on other
+    // streams): the tiles are shared out in rounds of at most that many, ONE launch of the equal share (512 tiles, limit 192 ->
+    // 171 workgroups x 3 tiles).  capped_grids > 0: only that many rounds are capped -- what the cap makes room for is over by
+    // then -- and the rest of the tiles go out in a second launch over the whole chip.  0: one launch over the whole chip.
     const int ntiles = (n + ROWS - 1) / ROWS;
-    // capped_grids > 0: only that many grids are capped -- what the cap makes room for is over by then -- and the rest of the
-    // tiles go out in one grid over the whole chip
-    const int limit = w->max_workgroups > 0 ? w->max_workgroups : ntiles;
-    int capped = ntiles;
-    if (w->max_workgroups > 0 && w->capped_grids > 0 && (long long)w->capped_grids * limit < ntiles)
-        capped = w->capped_grids * limit;
-    const int grids = (capped + limit - 1) / limit, cap = (capped + grids - 1) / grids;      // equal shares: 512 tiles, limit 192 -> 171, 171, 170
-    for (int t0 = 0; t0 < capped; t0 += cap) {
-        const int g = capped - t0 < cap ? capped - t0 : cap;
-        hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(g), dim3(256), LDS_BYTES, stream, n, t0, obs, action,
+    const int chip = cus[dev];
+    int capped = 0;
+    if (w->max_workgroups > 0) {
+        const int limit = w->max_workgroups;
+        capped = ntiles;
+        if (w->capped_grids > 0 && (long long)w->capped_grids * limit < ntiles) capped = w->capped_grids * limit;
+        const int rounds = (capped + limit - 1) / limit, g = (capped + rounds - 1) / rounds;
+        hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(g), dim3(256), LDS_BYTES, stream, n, 0, capped, obs, action,
                            reinterpret_cast<const unsigned char *>(w->split_ws),
                            reinterpret_cast<const unsigned char *>(w->split_ws_alt), out, act);
     }
-    if (capped < ntiles)
-        hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(ntiles - capped), dim3(256), LDS_BYTES, stream, n, capped, obs, action,
+    if (capped < ntiles) {
+        const int rest = ntiles - capped, rounds = (rest + chip - 1) / chip, g = (rest + rounds - 1) / rounds;
+        hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(g), dim3(256), LDS_BYTES, stream, n, capped, ntiles, obs, action,
                            reinterpret_cast<const unsigned char *>(w->split_ws),
                            reinterpret_cast<const unsigned char *>(w->split_ws_alt), out, act);
+    }
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 

@@ -65,6 +65,39 @@ def _agent(dev, z, capturable=False):
     return a
 
 
+def _ln_params(fl):
+    """The LayerNorm / action_value parameters the NEXT forward will use (cloned: the optimizer launch updates them in place)."""
+    out = []
+    for st in (fl.critic, fl.actor):
+        net = st.net
+        p = [net.bn1.weight, net.bn1.bias, net.bn2.weight, net.bn2.bias]
+        if st.critic:
+            p += [net.action_value.weight, net.action_value.bias]
+        out.append([t.detach().clone() for t in p])
+    return out
+
+
+def _relu_margin(fl, actions, params=None):
+    """Smallest |pre-activation| in front of any ReLU of the critic and the actor over the batch, from what the last forward
+    saved (x-hat * gamma + beta [+ action_value(a)]); params: _ln_params() taken BEFORE that forward's learn() call when the
+    optimizer has already run (default: the live parameters -- right between phase_a and the optimizer launches).  A unit closer to zero than the forward's own rounding (~1e-6, measured
+    between two builds of the same kernels) can fall on the other side than in the reference: its row's gradient then changes
+    by that unit's whole contribution -- ~6e-5 of a tensor's scale where all other errors are ~1e-6 (tools/dbg/grad_margin.py).
+    The parity tests keep their tight bound unless such a unit is PRESENT in the very forward they check."""
+    params = _ln_params(fl) if params is None else params
+    worst = float("inf")
+    for st, p in zip((fl.critic, fl.actor), params):
+        z1 = st.saved_t["xh1"] * p[0] + p[1]
+        z2 = st.saved_t["xh2"] * p[2] + p[3]
+        if st.critic:
+            z2 = z2 + actions.view(-1, 1) * p[4].view(1, -1) + p[5]
+        worst = min(worst, z1.abs().min().item(), z2.abs().min().item())
+    return worst
+
+
+_RELU_BOUNDARY = 3e-6
+
+
 @pytest.mark.parametrize("images", [True, False])
 def test_fused_learn_matches_reference_fixture_and_torch_path(gpu_device, images):
     """images: learn()'s 400x300 products on the f16 MFMA from pre-split fc2 images (the default) / on the exact-f32 MFMA."""
@@ -82,9 +115,12 @@ def test_fused_learn_matches_reference_fixture_and_torch_path(gpu_device, images
     torch_agent.learn_batch(s, a, r, s2, d)
     _check_snapshot(fused_agent, z, "after1", 1e-5)                 # vs the REFERENCE's learn()
     assert (fl.y - torch.tensor(z["target_y"], device=gpu_device)).abs().max().item() <= 1e-5 * np.abs(z["target_y"]).max()
+    boundary = False
     for _ in range(2):
+        before = _ln_params(fl)
         fl.learn_batch(s, a, r, s2, d8)
         torch_agent.learn_batch(s, a, r, s2, d)
+        boundary |= _relu_margin(fl, a, before) < _RELU_BOUNDARY
     _check_snapshot(fused_agent, z, "after3", 4e-5)
     for name in ("actor", "critic", "target_actor", "target_critic"):
         for (k, x), y in zip(getattr(fused_agent, name).state_dict().items(), getattr(torch_agent, name).state_dict().values()):
@@ -94,7 +130,11 @@ def test_fused_learn_matches_reference_fixture_and_torch_path(gpu_device, images
     fl.export_to_optimizers()
     st = fused_agent.critic.optimizer.state[fused_agent.critic.fc2.weight]
     ref = torch_agent.critic.optimizer.state[torch_agent.critic.fc2.weight]
-    assert float(st["step"]) == 3 and torch.allclose(st["exp_avg"], ref["exp_avg"], rtol=1e-3, atol=1e-7)
+    assert float(st["step"]) == 3
+    if boundary:    # a ReLU unit within rounding of zero in one of these forwards (see _relu_margin): scale-relative bound
+        assert (st["exp_avg"] - ref["exp_avg"]).abs().max().item() <= 1e-3 * ref["exp_avg"].abs().max().item()
+    else:
+        assert torch.allclose(st["exp_avg"], ref["exp_avg"], rtol=1e-3, atol=1e-7)
     fl2 = FusedLearner(fused_agent, 256)
     fl2.import_from_optimizers()
     assert int(fl2.step_dev.item()) == 3 and torch.equal(fl2.critic.m, fl.critic.m)
@@ -122,11 +162,14 @@ def test_fused_gradients_and_losses_match_the_reference(gpu_device, images):
     for i in (1, 2, 3):
         # the data-parallel pieces leave each site's gradient in place before its optimizer launch (phase_a / phase_b)
         fl.phase_a(s, a, r, s2, d8, fuse_adam=False)
-        _check_grads(z, i, "critic", named(fl.critic))
+        # 3e-5 of each tensor's scale (measured: <= 1e-6) -- 1e-4 only where this very forward holds a ReLU unit within
+        # rounding of zero (_relu_margin; with the f16-image products that happens at step 3: one unit of row 112)
+        rtol = 3e-5 if _relu_margin(fl, a) >= _RELU_BOUNDARY else 1e-4
+        _check_grads(z, i, "critic", named(fl.critic), rtol)
         loss_c = torch.mean((fl.q - fl.y) ** 2).item()
         assert abs(loss_c - float(z[f"loss{i}/critic"])) <= 1e-5 * float(z[f"loss{i}/critic"])
         fl.phase_b(s, separate_adam=True)
-        _check_grads(z, i, "actor", named(fl.actor))
+        _check_grads(z, i, "actor", named(fl.actor), rtol)
         loss_a = -fl.q_pi.mean().item()
         assert abs(loss_a - float(z[f"loss{i}/actor"])) <= 2e-5 * max(0.1, abs(float(z[f"loss{i}/actor"])))
         fl.phase_c()

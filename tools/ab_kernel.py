@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
 out = []
-for n in (65536, 1048576):
+for n in ([int(x) for x in sys.argv[1:]] or [65536, 1048576]):
     env = TruckTrailerVecEnv(n); env.reset(seed=1)
     for _ in range(100): env.step_random(7, auto_reset=True)
     best = 1e9

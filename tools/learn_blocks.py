@@ -16,13 +16,30 @@ from ddpg_trucktrailer_amd.agent import Agent
 from ddpg_trucktrailer_amd.fused_learn import FusedLearner
 
 NAMES = ["k_fwd_multi", "k_bwd_rows_pair", "k_bwd_weights<critic>", "k_fwd_small<critic>", "k_bwd_weights<actor>"]
-GRID = [64, 32, 133 + 25 + 57, 16, 133 + 25 + 47]
+GRID = [64, 32, 133 + 25 + 52, 16, 133 + 25 + 42]
 
 
 def read(lib):
     buf = (C.c_ulonglong * (6 * 1024))()
     assert lib.tt_debug_kblocks(buf) == 0
     return np.array(buf, dtype=np.int64).reshape(6, 512, 2)
+
+
+def phases(lib):
+    """Phase stamps of workgroup 0 (a dW2 block) of the two weight-gradient launches and of workgroup 0 of the row kernels."""
+    buf = (C.c_ulonglong * 32)()
+    if not hasattr(lib, "tt_debug_wst") or lib.tt_debug_wst(buf) != 0:
+        return
+    w = np.array(buf, dtype=np.int64).reshape(2, 16)
+    names = ["loads issued -> factors", "factors -> MFMAs done", "pow + partial stores", "barrier", "sums + Adam", "image patch", "end barrier"]
+    for k, net in enumerate(("critic", "actor")):
+        d = np.diff(w[k, :8]) / 100.0
+        print(f"  k_bwd_weights<{net}> workgroup 0 phases (us):", ", ".join(f"{n} {x:.2f}" for n, x in zip(names, d)))
+    st = (C.c_ulonglong * 32)()
+    lib.tt_debug_stamps(st)
+    f = list(st)
+    print("  row kernels, workgroup 0 (us): fwd layer1 %.2f LN1 %.2f layer2 %.2f epilogue %.2f | bwd phaseA %.2f phaseB %.2f phaseC %.2f" % (
+        tuple((f[i + 1] - f[i]) / 100 for i in range(4)) + tuple((f[i + 1] - f[i]) / 100 for i in (8, 9, 10))))
 
 
 def report(a, title):
@@ -64,6 +81,7 @@ def main():
         g.replay(); g.replay(); g.replay()
         torch.cuda.synchronize()
         report(read(lib), f"learn() alone, third of three back-to-back hipGraph replays (repeat {rep})")
+        phases(lib)
     from ddpg_trucktrailer_amd.rollout import DDPGRollout
     from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
@@ -75,6 +93,7 @@ def main():
         loop.run(20)
         torch.cuda.synchronize()
         report(read(lib), f"learn() of the LAST step of a 20-step graph of the N = {n} loop (policy grids beside it) (repeat {rep})")
+        phases(lib)
 
 
 if __name__ == "__main__":
