@@ -55,7 +55,8 @@ class TTFwdJob(C.Structure):
 class TTTdInput(C.Structure):
     _fields_ = [("z_state", C.c_void_p), ("mu_target", C.c_void_p), ("target_critic", C.POINTER(TTMlpWeights)),
                 ("reward", C.c_void_p), ("done", C.c_void_p), ("gamma", C.c_float), ("reserved_", C.c_float),
-                ("y_out", C.c_void_p), ("q_out", C.c_void_p), ("step_dev", C.c_void_p), ("window_dev", C.c_void_p)]
+                ("y_out", C.c_void_p), ("q_out", C.c_void_p), ("step_dev", C.c_void_p), ("window_dev", C.c_void_p),
+                ("bias_corr_out", C.c_void_p), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float)]
 
 
 class TTSideBuffer(C.Structure):
@@ -141,9 +142,9 @@ _SIGNATURES = {
                                             C.POINTER(TTMlpBwdWs), _P]),
     "tt_mlp_backward_weights": (C.c_int, [_I, _I, _P, _P, C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights),
                                           _P, _P, C.c_float, _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
-                                          C.c_float, C.c_float, C.POINTER(TTFc2Images), _P]),
+                                          C.c_float, C.c_float, C.POINTER(TTFc2Images), _P, _P]),
     "tt_adam_soft_update": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
-                                      C.c_float, C.c_float, C.POINTER(TTFc2Images), _P]),
+                                      C.c_float, C.c_float, C.POINTER(TTFc2Images), _P, _P]),
     "tt_mlp_fc2_image_bytes": (C.c_uint64, []),
     "tt_mlp_fc2_image_pack": (C.c_int, [C.POINTER(TTMlpWeights), _P]),
     "tt_td_target": (C.c_int, [_I, _P, _P, _P, C.c_float, _P, _P, _P]),

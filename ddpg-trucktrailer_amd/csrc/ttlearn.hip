@@ -191,6 +191,28 @@ __device__ __forceinline__ void cross_wave_sum2(float *red, int wave, int l4, in
 // The same trick on the N side ("column group"): lane l loads float4 W[k][c0 + 4*(l&15) .. +3] and uses component t
 // as the B operand of output tile t, whose 16 columns are c0 + 4*(l&15) + t.
 
+// Row phases (LayerNorms, head, their backward): a wave owns two rows and its lanes take the columns FOUR AT A TIME --
+// columns 4 lane .. 4 lane + 3 and 256 + 4 lane .. + 3 -- so that every access of a row is a 16-byte one (LDS tile, saved
+// activations, per-column vectors) and the two f16 planes leave as 8-byte stores: a quarter of the memory instructions of a
+// lane-strided walk (column lane + 64 i), and no per-column branches.
+constexpr int RV = 2;                                            // float4 groups of a row per lane
+__device__ __forceinline__ int rv_col(const int lane, const int i) { return 4 * lane + 256 * i; }
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4_ld(const float *p, const bool ok) {     // 16-byte aligned p; zeros where !ok
+    return ok ? *reinterpret_cast<const float4 *>(p) : f4_zero();
+}
+__device__ __forceinline__ float f4_sum(const float4 v) { return (v.x + v.y) + (v.z + v.w); }
+using h2v = __attribute__((ext_vector_type(2))) _Float16;
+// four f32 -> their f16 pieces (round to nearest): h = rn16(x), m = rn16(x - h), as two 8-byte groups
+__device__ __forceinline__ void split4(const float4 x, uint2 &ph, uint2 &pm) {
+    h2v a, b, c, d;
+    a[0] = (_Float16)x.x; a[1] = (_Float16)x.y; b[0] = (_Float16)x.z; b[1] = (_Float16)x.w;
+    c[0] = (_Float16)(x.x - (float)a[0]); c[1] = (_Float16)(x.y - (float)a[1]);
+    d[0] = (_Float16)(x.z - (float)b[0]); d[1] = (_Float16)(x.w - (float)b[1]);
+    ph = make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
+    pm = make_uint2(__builtin_bit_cast(uint32_t, c), __builtin_bit_cast(uint32_t, d));
+}
+
 // forward on a small batch.  out [B]: q (critic) or mu = tanh(.) (actor).  dq_da [B] (critic, optional):
 // dQ/da = sum_j wq[j] * [z_j > 0] * wa[j], which is all of the critic the actor's gradient needs because the action
 // enters after LayerNorm2 (networks.py:62-66).
@@ -210,23 +232,15 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
 
     STAMP(0);
     constexpr int MT1 = (NT1 + NW - 1) / NW, MT2 = (NT2 + NW - 1) / NW;
-    constexpr int C1 = (H1 + 63) / 64, C2 = (H2 + 63) / 64;     // columns per lane in the row phases: 7 and 5
     // every per-column vector this lane will need, loaded NOW: the uses sit behind barriers, which the compiler cannot
     // move a load across, so each would cost an exposed L2 round trip there
-    float pb1[C1], pg1[C1], pbe1[C1], pb2[C2], pg2[C2], pbe2[C2], pw3[C2], pwa[C2], pba[C2];
+    // (layer 1's vectors here; layer 2's are requested where layer 2 starts and land behind its products)
+    float4 pb1[RV], pg1[RV], pbe1[RV], pb2[RV], pg2[RV], pbe2[RV], pw3[RV], pwa[RV], pba[RV];
 #pragma unroll
-    for (int i = 0; i < C1; ++i) {
-        const int c = lane + 64 * i;
-        const bool real = c < H1;
-        pb1[i] = real ? W.b1[c] : 0.f; pg1[i] = real ? W.g1[c] : 0.f; pbe1[i] = real ? W.be1[c] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < C2; ++i) {
-        const int c = lane + 64 * i;
-        const bool real = c < H2;
-        pb2[i] = real ? W.b2[c] : 0.f; pg2[i] = real ? W.g2[c] : 0.f; pbe2[i] = real ? W.be2[c] : 0.f;
-        pw3[i] = real ? W.w3[c] : 0.f;
-        pwa[i] = (CRITIC && real) ? W.wa[c] : 0.f; pba[i] = (CRITIC && real) ? W.ba[c] : 0.f;
+    for (int i = 0; i < RV; ++i) {
+        const int c = rv_col(lane, i);
+        const bool r1 = c < H1;
+        pb1[i] = f4_ld(W.b1 + c, r1); pg1[i] = f4_ld(W.g1 + c, r1); pbe1[i] = f4_ld(W.be1 + c, r1);
     }
     // ---- layer 1 (K = 23): operands straight from global; this wave's column tiles t = wave, wave+NW, ...
     f32x4 acc1[MT1];
@@ -255,6 +269,23 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
         }
     }
     STAMP(1);
+    // The first group of fc2 fragments (three k32 steps of this wave's tiles, straight from L2) is requested HERE: it does not
+    // depend on the activations, and requested where layer 2 starts it cost that phase one exposed L2 round trip (~1 us)
+    constexpr int GU_F = 3;
+    const bool img = W.img != nullptr;                     // (uniform over the launch)
+    const int nt_f = (NT2 - wave + NW - 1) / NW;          // layer-2 tiles of this wave: 3 (waves 0..3) or 2
+    f16x8 bpre[GU_F][MT2][2];
+    if (img) {
+#pragma unroll
+        for (int u = 0; u < GU_F; ++u)
+#pragma unroll
+            for (int i = 0; i < MT2; ++i)
+                if (i < nt_f) {
+                    const _Float16 *b = W.img + ((size_t)min(wave + NW * i, NT2 - 1) * FW_STEPS * 64 + lane) * 8 + 512 * u;
+                    bpre[u][i][0] = *reinterpret_cast<const f16x8 *>(b);
+                    bpre[u][i][1] = *reinterpret_cast<const f16x8 *>(b + IMG_FWD);
+                }
+    }
     // accumulator element [i][r] is row l4*4 + r, column (wave + NW*i)*16 + l15
 #pragma unroll
     for (int i = 0; i < MT1; ++i) {
@@ -268,63 +299,76 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
     // bias, LayerNorm(400) (biased variance, eps 1e-5), ReLU for this wave's two rows.  With an fc2 image the rows leave as
     // the two f16 planes of the layer-2 operand, which share the buffer with the f32 tile: every wave has read its rows
     // before any plane is written
-    const bool img = W.img != nullptr;                     // (uniform over the launch)
     _Float16 *const ap_s = reinterpret_cast<_Float16 *>(h1_s);          // [2 planes][16][HSH]
-    float xr[TR / NW][C1];
+    float4 xr[TR / NW][RV];
 #pragma unroll
     for (int rr = 0; rr < TR / NW; ++rr) {
         const int lr = wave * (TR / NW) + rr;
 #pragma unroll
-        for (int i = 0; i < C1; ++i) {
-            const int c = lane + 64 * i;
-            xr[rr][i] = c < H1 ? h1_s[lr * HS1 + c] + pb1[i] : 0.f;
+        for (int i = 0; i < RV; ++i) {
+            const int c = rv_col(lane, i);
+            const bool ok = c < H1;
+            const float4 t = *reinterpret_cast<const float4 *>(&h1_s[lr * HS1 + (ok ? c : 0)]);
+            xr[rr][i] = ok ? make_float4(t.x + pb1[i].x, t.y + pb1[i].y, t.z + pb1[i].z, t.w + pb1[i].w) : f4_zero();
         }
     }
     if (img) lds_barrier();
 #pragma unroll
     for (int rr = 0; rr < TR / NW; ++rr) {
         const int lr = wave * (TR / NW) + rr, row = row0 + lr;
-        float x[C1], s1 = 0.f;
-#pragma unroll
-        for (int i = 0; i < C1; ++i) {
-            x[i] = xr[rr][i];
-            s1 += x[i];
-        }
-        const float mean = wave_sum64(s1) * (1.f / H1);
+        const float mean = wave_sum64(f4_sum(xr[rr][0]) + f4_sum(xr[rr][1])) * (1.f / H1);
+        float4 dv[RV];
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < C1; ++i) {
-            const float d = lane + 64 * i < H1 ? x[i] - mean : 0.f;
-            ss = fmaf(d, d, ss);
+        for (int i = 0; i < RV; ++i) {
+            const bool ok = rv_col(lane, i) < H1;
+            const float4 x = xr[rr][i];
+            dv[i] = ok ? make_float4(x.x - mean, x.y - mean, x.z - mean, x.w - mean) : f4_zero();
+            ss = fmaf(dv[i].x, dv[i].x, ss); ss = fmaf(dv[i].y, dv[i].y, ss);
+            ss = fmaf(dv[i].z, dv[i].z, ss); ss = fmaf(dv[i].w, dv[i].w, ss);
         }
         const float rstd = rsqrtf(wave_sum64(ss) * (1.f / H1) + 1e-5f);
         if (sv.rstd1 && lane == 0 && row < n) sv.rstd1[row] = rstd;
+        const bool save = sv.xh1 && row < n;
 #pragma unroll
-        for (int i = 0; i < C1; ++i) {
-            const int c = lane + 64 * i;
+        for (int i = 0; i < RV; ++i) {
+            const int c = rv_col(lane, i);
             if (c < H1) {
-                const float xh = (x[i] - mean) * rstd;
-                const float h = fmaxf(fmaf(xh, pg1[i], pbe1[i]), 0.f);
+                const float4 xh = make_float4(dv[i].x * rstd, dv[i].y * rstd, dv[i].z * rstd, dv[i].w * rstd);
+                const float4 h = make_float4(fmaxf(fmaf(xh.x, pg1[i].x, pbe1[i].x), 0.f), fmaxf(fmaf(xh.y, pg1[i].y, pbe1[i].y), 0.f),
+                                             fmaxf(fmaf(xh.z, pg1[i].z, pbe1[i].z), 0.f), fmaxf(fmaf(xh.w, pg1[i].w, pbe1[i].w), 0.f));
                 if (img) {
-                    const float hs = h * SXL;
-                    const _Float16 hh = (_Float16)hs;
-                    ap_s[lr * HSH + c] = hh;
-                    ap_s[TR * HSH + lr * HSH + c] = (_Float16)(hs - (float)hh);
+                    uint2 ph, pm;
+                    split4(make_float4(h.x * SXL, h.y * SXL, h.z * SXL, h.w * SXL), ph, pm);
+                    *reinterpret_cast<uint2 *>(ap_s + lr * HSH + c) = ph;
+                    *reinterpret_cast<uint2 *>(ap_s + TR * HSH + lr * HSH + c) = pm;
                 } else {
-                    h1_s[lr * HS1 + c] = h;
+                    *reinterpret_cast<float4 *>(&h1_s[lr * HS1 + c]) = h;
                 }
-                if (sv.xh1 && row < n) {
-                    sv.xh1[(size_t)row * H1 + c] = xh;
-                    sv.h1[(size_t)row * H1 + c] = h;
+                if (save) {
+                    *reinterpret_cast<float4 *>(sv.xh1 + (size_t)row * H1 + c) = xh;
+                    *reinterpret_cast<float4 *>(sv.h1 + (size_t)row * H1 + c) = h;
                 }
             } else if (img && c < K2P) {                   // K padding of the planes (inputs 400..415)
-                ap_s[lr * HSH + c] = (_Float16)0.f;
-                ap_s[TR * HSH + lr * HSH + c] = (_Float16)0.f;
+                *reinterpret_cast<uint2 *>(ap_s + lr * HSH + c) = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2 *>(ap_s + TR * HSH + lr * HSH + c) = make_uint2(0u, 0u);
             }
         }
     }
     lds_barrier();   // the 16 x 400 activation tile is complete
     STAMP(2);
+    // layer 2's per-column vectors: requested behind the LAST group of fc2 fragments (the prefetch registers are free by then),
+    // so that they land behind that group's products
+    auto load_l2_vectors = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < RV; ++i) {
+            const int c = rv_col(lane, i);
+            const bool r2 = c < H2;
+            pb2[i] = f4_ld(W.b2 + c, r2); pg2[i] = f4_ld(W.g2 + c, r2); pbe2[i] = f4_ld(W.be2 + c, r2);
+            pw3[i] = f4_ld(W.w3 + c, r2);
+            pwa[i] = f4_ld(W.wa + c, CRITIC && r2); pba[i] = f4_ld(W.ba + c, CRITIC && r2);
+        }
+    };
 
     // ---- layer 2: this wave's column tiles t = wave, wave+NW, ... (3 or 2 of the 20); A from the LDS tile (one
     // ds_read_b128 per k16 step), B = fc2 rows straight from L2 (one float4 per tile per k16 step), k visited in
@@ -344,7 +388,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
         // A = the planes (one ds_read_b128 per plane and k32 step), B = this wave's rows of the image's [n][k] half straight
         // from L2 (16 B per plane, tile and step), three MFMAs per tile and step, small terms first; the fragments of the
         // NEXT three steps are requested before the current three issue
-        const int nt = (NT2 - wave + NW - 1) / NW;         // tiles of this wave: 3 (waves 0..3) or 2
+        const int nt = nt_f;
         const _Float16 *ah = ap_s + l15 * HSH + 8 * l4;
         const _Float16 *bh[MT2];
 #pragma unroll
@@ -363,10 +407,15 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
                     }
                 }
         };
-        load_group(0, bcur);
+        static_assert(GU == GU_F, "the prefetched group is group 0");
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+#pragma unroll
+            for (int i = 0; i < MT2; ++i) { bcur[u][i][0] = bpre[u][i][0]; bcur[u][i][1] = bpre[u][i][1]; }
 #pragma unroll
         for (int g = 0; g < NGRP; ++g) {
             if (g + 1 < NGRP) load_group(g + 1, bnxt);
+            else load_l2_vectors();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
@@ -391,6 +440,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
 #pragma unroll
         for (int i = 0; i < MT2; ++i) acc2[i] *= UNSC_L;
     } else {
+    load_l2_vectors();
     const float *arow = h1_s + l15 * HS1 + 4 * l4;
 #pragma unroll 5
     for (int c = 0; c < H1 / 16; ++c) {
@@ -435,19 +485,21 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
 #pragma unroll
     for (int rr = 0; rr < TR / NW; ++rr) {
         const int lr = wave * (TR / NW) + rr, row = row0 + lr;
-        float x[C2], s1 = 0.f;
+        float4 x[RV];
 #pragma unroll
-        for (int i = 0; i < C2; ++i) {
-            const int c = lane + 64 * i;
-            x[i] = c < H2 ? z_s[lr * DS + c] + pb2[i] : 0.f;
-            s1 += x[i];
+        for (int i = 0; i < RV; ++i) {
+            const int c = rv_col(lane, i);
+            const bool ok = c < H2;
+            const float4 t = *reinterpret_cast<const float4 *>(&z_s[lr * DS + (ok ? c : 0)]);
+            x[i] = ok ? make_float4(t.x + pb2[i].x, t.y + pb2[i].y, t.z + pb2[i].z, t.w + pb2[i].w) : f4_zero();
         }
-        const float mean = wave_sum64(s1) * (1.f / H2);
+        const float mean = wave_sum64(f4_sum(x[0]) + f4_sum(x[1])) * (1.f / H2);
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < C2; ++i) {
-            const float d = lane + 64 * i < H2 ? x[i] - mean : 0.f;
-            ss = fmaf(d, d, ss);
+        for (int i = 0; i < RV; ++i) {
+            const bool ok = rv_col(lane, i) < H2;
+            x[i] = ok ? make_float4(x[i].x - mean, x[i].y - mean, x[i].z - mean, x[i].w - mean) : f4_zero();      // deviations
+            ss = fmaf(x[i].x, x[i].x, ss); ss = fmaf(x[i].y, x[i].y, ss); ss = fmaf(x[i].z, x[i].z, ss); ss = fmaf(x[i].w, x[i].w, ss);
         }
         const float rstd = rsqrtf(wave_sum64(ss) * (1.f / H2) + 1e-5f);
         if (sv.rstd2 && lane == 0 && row < n) sv.rstd2[row] = rstd;
@@ -456,27 +508,38 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
             // enters; the TD prologue of the critic's backward (or k_head_td) finishes q once the action is known, so
             // this pass can run NEXT TO the actor pass that produces it
 #pragma unroll
-            for (int i = 0; i < C2; ++i) {
-                const int c = lane + 64 * i;
-                if (c < H2 && row < n) z_state[(size_t)row * H2 + c] = fmaf((x[i] - mean) * rstd, pg2[i], pbe2[i]);
+            for (int i = 0; i < RV; ++i) {
+                const int c = rv_col(lane, i);
+                if (c < H2 && row < n)
+                    *reinterpret_cast<float4 *>(z_state + (size_t)row * H2 + c) =
+                        make_float4(fmaf(x[i].x * rstd, pg2[i].x, pbe2[i].x), fmaf(x[i].y * rstd, pg2[i].y, pbe2[i].y),
+                                    fmaf(x[i].z * rstd, pg2[i].z, pbe2[i].z), fmaf(x[i].w * rstd, pg2[i].w, pbe2[i].w));
             }
             continue;
         }
         const float av = avs[rr];
+        const bool save = sv.xh2 && row < n;
         float dot = 0.f, dqa = 0.f;
 #pragma unroll
-        for (int i = 0; i < C2; ++i) {
-            const int c = lane + 64 * i;
+        for (int i = 0; i < RV; ++i) {
+            const int c = rv_col(lane, i);
             if (c < H2) {
-                const float xh = (x[i] - mean) * rstd;
-                float z = fmaf(xh, pg2[i], pbe2[i]);
-                if (CRITIC) z += fmaf(av, pwa[i], pba[i]);
-                const float h = fmaxf(z, 0.f);
-                dot = fmaf(h, pw3[i], dot);
-                if (CRITIC) dqa = fmaf(z > 0.f ? pw3[i] : 0.f, pwa[i], dqa);
-                if (sv.xh2 && row < n) {
-                    sv.xh2[(size_t)row * H2 + c] = xh;
-                    sv.h2[(size_t)row * H2 + c] = h;
+                const float xhv[4] = {x[i].x * rstd, x[i].y * rstd, x[i].z * rstd, x[i].w * rstd};
+                const float gv[4] = {pg2[i].x, pg2[i].y, pg2[i].z, pg2[i].w}, bev[4] = {pbe2[i].x, pbe2[i].y, pbe2[i].z, pbe2[i].w};
+                const float w3v[4] = {pw3[i].x, pw3[i].y, pw3[i].z, pw3[i].w};
+                const float wav[4] = {pwa[i].x, pwa[i].y, pwa[i].z, pwa[i].w}, bav[4] = {pba[i].x, pba[i].y, pba[i].z, pba[i].w};
+                float hv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float z = fmaf(xhv[q], gv[q], bev[q]);
+                    if (CRITIC) z += fmaf(av, wav[q], bav[q]);
+                    hv[q] = fmaxf(z, 0.f);
+                    dot = fmaf(hv[q], w3v[q], dot);
+                    if (CRITIC) dqa = fmaf(z > 0.f ? w3v[q] : 0.f, wav[q], dqa);
+                }
+                if (save) {
+                    *reinterpret_cast<float4 *>(sv.xh2 + (size_t)row * H2 + c) = make_float4(xhv[0], xhv[1], xhv[2], xhv[3]);
+                    *reinterpret_cast<float4 *>(sv.h2 + (size_t)row * H2 + c) = make_float4(hv[0], hv[1], hv[2], hv[3]);
                 }
             }
         }
@@ -557,7 +620,24 @@ struct TdIn {
     float gamma;
     float *__restrict__ y_out, *__restrict__ q_out;
     long long *__restrict__ step_dev, *__restrict__ window_dev;
+    float *__restrict__ bc_out;        // Adam's bias corrections of the new step (tt_td_input.bias_corr_out) or nullptr
+    float beta1, beta2;
+    int separate_tick;                 // 1: the counters are advanced by clock_tick() on a workgroup of its own, not by block 0
 };
+
+// Advance the learn-step (and sampling-window) counter; leave torch.optim.Adam's bias corrections of the new step: two f64
+// pow() here, once, instead of in every thread of the two optimizer launches (~1.1 us on each launch's critical path).
+__device__ inline void clock_tick(const TdIn &td) {
+    long long t = 0;
+    if (td.step_dev) { t = *td.step_dev + 1; *td.step_dev = t; }
+    if (td.window_dev) *td.window_dev += 1;
+    if (td.bc_out && td.step_dev) {
+        td.bc_out[1] = td.beta1; td.bc_out[2] = td.beta2;
+        td.bc_out[3] = (float)(1.0 - pow((double)td.beta1, (double)t));
+        td.bc_out[4] = (float)(1.0 - pow((double)td.beta2, (double)t));
+        td.bc_out[0] = __int_as_float((int)t);
+    }
+}
 
 template <bool CRITIC>
 __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const float scale,
@@ -572,21 +652,21 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
     _Float16 *const dxp_s = reinterpret_cast<_Float16 *>(dx2_s);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     STAMP(8);
-    // ---- phase A: head, ReLU and LayerNorm2 backward; wave w owns rows 2w, 2w+1; lanes stride the 300 columns.
-    // Every load of both rows is issued before the first store: the outputs are plain pointers inside a struct, so the
-    // compiler must assume a store may alias a later load and would otherwise serialise the two rows' round trips.
-    constexpr int RPW = TR / NW, C2 = (H2 + 63) / 64;
-    float w3c[C2], g2c[C2], h2v[RPW][C2], xh[RPW][C2], rs[RPW], gin[RPW], yin[RPW], outv[RPW];
-    float zt[RPW][C2], wat[C2], bat[C2], w3t[C2], mut[RPW], rt[RPW], b3t = 0.f;
+    // ---- phase A: head, ReLU and LayerNorm2 backward; wave w owns rows 2w, 2w+1; a lane takes the 300 columns four at a
+    // time (see RV).  Every load of both rows is issued before the first store: the outputs are plain pointers inside a struct,
+    // so the compiler must assume a store may alias a later load and would otherwise serialise the two rows' round trips.
+    constexpr int RPW = TR / NW;
+    float4 w3c[RV], g2c[RV], h2v[RPW][RV], xh[RPW][RV], zt[RPW][RV], wat[RV], bat[RV], w3t[RV];
+    float rs[RPW], gin[RPW], yin[RPW], outv[RPW], mut[RPW], rt[RPW], b3t = 0.f;
     bool dt[RPW];
     const bool with_td = CRITIC && td.z_state;               // (uniform over the launch)
 #pragma unroll
-    for (int i = 0; i < C2; ++i) {
-        const int c = lane + 64 * i;
+    for (int i = 0; i < RV; ++i) {
+        const int c = rv_col(lane, i);
         const bool real = c < H2;
-        w3c[i] = real ? W.w3[c] : 0.f; g2c[i] = real ? W.g2[c] : 0.f;
-        wat[i] = (with_td && real) ? td.wa[c] : 0.f; bat[i] = (with_td && real) ? td.ba[c] : 0.f;
-        w3t[i] = (with_td && real) ? td.w3[c] : 0.f;
+        w3c[i] = f4_ld(W.w3 + c, real); g2c[i] = f4_ld(W.g2 + c, real);
+        wat[i] = f4_ld(td.wa + c, with_td && real); bat[i] = f4_ld(td.ba + c, with_td && real);
+        w3t[i] = f4_ld(td.w3 + c, with_td && real);
     }
     if (with_td) b3t = td.b3[0];
 #pragma unroll
@@ -601,18 +681,32 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
         rt[rr] = (ok && with_td) ? td.r[row] : 0.f;
         dt[rr] = (ok && with_td) ? td.done[row] != 0 : false;
 #pragma unroll
-        for (int i = 0; i < C2; ++i) {
-            const int c = lane + 64 * i;
+        for (int i = 0; i < RV; ++i) {
+            const int c = rv_col(lane, i);
             const bool real = ok && c < H2;
             const size_t q = (size_t)row * H2 + c;
-            h2v[rr][i] = real ? sv.h2[q] : 0.f;
-            xh[rr][i] = real ? sv.xh2[q] : 0.f;
-            zt[rr][i] = (real && with_td) ? td.z_state[q] : 0.f;
+            h2v[rr][i] = f4_ld(sv.h2 + q, real);
+            xh[rr][i] = f4_ld(sv.xh2 + q, real);
+            zt[rr][i] = f4_ld(td.z_state + q, real && with_td);
         }
     }
-    if (with_td && blockIdx.x == 0 && tid == 0) {
+    if (with_td && blockIdx.x == 0 && tid == 0 && !td.separate_tick) {
         if (td.step_dev) *td.step_dev += 1;
         if (td.window_dev) *td.window_dev += 1;      // a pipelined loop's sampling window moves on (read by LATER launches only)
+    }
+    // phase B's first group of fc2 fragments (two k32 steps of this wave's four tiles, straight from L2) is requested HERE,
+    // behind phase A's own loads: it depends on nothing this kernel computes
+    constexpr int GU_B = 2;
+    f16x8 bpre[GU_B][4][2];
+    if (img && wave < NG) {
+        const _Float16 *bh0 = W.img + 2 * IMG_FWD + ((size_t)wave * 4 * BW_STEPS * 64 + lane) * 8;
+#pragma unroll
+        for (int u = 0; u < GU_B; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bpre[u][t][0] = *reinterpret_cast<const f16x8 *>(bh0 + (size_t)(t * BW_STEPS + u) * 512);
+                bpre[u][t][1] = *reinterpret_cast<const f16x8 *>(bh0 + IMG_T + (size_t)(t * BW_STEPS + u) * 512);
+            }
     }
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
@@ -622,7 +716,12 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
         if (with_td) {
             float dot = 0.f;
 #pragma unroll
-            for (int i = 0; i < C2; ++i) dot = fmaf(fmaxf(zt[rr][i] + fmaf(mut[rr], wat[i], bat[i]), 0.f), w3t[i], dot);
+            for (int i = 0; i < RV; ++i) {
+                dot = fmaf(fmaxf(zt[rr][i].x + fmaf(mut[rr], wat[i].x, bat[i].x), 0.f), w3t[i].x, dot);
+                dot = fmaf(fmaxf(zt[rr][i].y + fmaf(mut[rr], wat[i].y, bat[i].y), 0.f), w3t[i].y, dot);
+                dot = fmaf(fmaxf(zt[rr][i].z + fmaf(mut[rr], wat[i].z, bat[i].z), 0.f), w3t[i].z, dot);
+                dot = fmaf(fmaxf(zt[rr][i].w + fmaf(mut[rr], wat[i].w, bat[i].w), 0.f), w3t[i].w, dot);
+            }
             const float q = wave_sum64(dot) + b3t;
             y_td = dt[rr] ? rt[rr] : fmaf(td.gamma, q, rt[rr]);
             if (ok && lane == 0) {
@@ -637,50 +736,57 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
             if (mode == 3) g = 1.f;       // unit backward: every per-row gradient below is linear in g (see k_bwd_rows_pair)
             dpre = g;
         }
-        float dxh[C2], s1 = 0.f, s2 = 0.f;
+        float4 dxh[RV];
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < C2; ++i) {
-            const int c = lane + 64 * i;
-            dxh[i] = 0.f;
+        for (int i = 0; i < RV; ++i) {
+            const int c = rv_col(lane, i);
+            dxh[i] = f4_zero();
             if (c < H2 && ok) {
-                const float dz = h2v[rr][i] > 0.f ? dpre * w3c[i] : 0.f;
-                o.dz[(size_t)row * H2 + c] = dz;
-                dxh[i] = dz * g2c[i];
-                s1 += dxh[i];
-                s2 = fmaf(dxh[i], xh[rr][i], s2);
+                const float4 dz = make_float4(h2v[rr][i].x > 0.f ? dpre * w3c[i].x : 0.f, h2v[rr][i].y > 0.f ? dpre * w3c[i].y : 0.f,
+                                              h2v[rr][i].z > 0.f ? dpre * w3c[i].z : 0.f, h2v[rr][i].w > 0.f ? dpre * w3c[i].w : 0.f);
+                *reinterpret_cast<float4 *>(o.dz + (size_t)row * H2 + c) = dz;
+                dxh[i] = make_float4(dz.x * g2c[i].x, dz.y * g2c[i].y, dz.z * g2c[i].z, dz.w * g2c[i].w);
+                s1 += f4_sum(dxh[i]);
+                s2 = fmaf(dxh[i].x, xh[rr][i].x, s2); s2 = fmaf(dxh[i].y, xh[rr][i].y, s2);
+                s2 = fmaf(dxh[i].z, xh[rr][i].z, s2); s2 = fmaf(dxh[i].w, xh[rr][i].w, s2);
             }
         }
         s1 = wave_sum64(s1) * (1.f / H2);
         s2 = wave_sum64(s2) * (1.f / H2);
-        float vv[C2];
+        float4 vv[RV];
 #pragma unroll
-        for (int i = 0; i < C2; ++i) {
-            const int c = lane + 64 * i;
-            float v = 0.f;
+        for (int i = 0; i < RV; ++i) {
+            const int c = rv_col(lane, i);
+            float4 v = f4_zero();
             if (c < H2 && ok) {
-                v = rs[rr] * (dxh[i] - s1 - xh[rr][i] * s2);
-                o.dx2[(size_t)row * H2 + c] = v;
+                v = make_float4(rs[rr] * (dxh[i].x - s1 - xh[rr][i].x * s2), rs[rr] * (dxh[i].y - s1 - xh[rr][i].y * s2),
+                                rs[rr] * (dxh[i].z - s1 - xh[rr][i].z * s2), rs[rr] * (dxh[i].w - s1 - xh[rr][i].w * s2));
+                *reinterpret_cast<float4 *>(o.dx2 + (size_t)row * H2 + c) = v;
             }
             vv[i] = v;
-            if (!img && c < DS) dx2_s[lr * DS + c] = v;     // zero in the K padding (columns 300..307)
+            if (!img && c < DS) *reinterpret_cast<float4 *>(&dx2_s[lr * DS + c]) = v;     // zero in the K padding (columns 300..307)
         }
         if (img) {
             // the row as two f16 planes, scaled by the power of two that puts its largest entry in [2^12, 2^13): gradients
             // are far below f16's normal range as they come
             float mx = 0.f;
 #pragma unroll
-            for (int i = 0; i < C2; ++i) mx = fmaxf(mx, fabsf(vv[i]));
+            for (int i = 0; i < RV; ++i)
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(vv[i].x), fabsf(vv[i].y))), fmaxf(fabsf(vv[i].z), fabsf(vv[i].w)));
             mx = wave_max64(mx);
             const int e = (__builtin_bit_cast(int, mx) >> 23) & 0xff;
             const int se = min(max(266 - e, 1), 253);
             const float sc = __builtin_bit_cast(float, se << 23), inv = __builtin_bit_cast(float, (254 - se) << 23);
 #pragma unroll
-            for (int i = 0; i < C2; ++i) {                  // c < 320: every plane entry, zeros beyond column 299
-                const int c = lane + 64 * i;
-                const float hs = vv[i] * sc;
-                const _Float16 hh = (_Float16)hs;
-                dxp_s[lr * DSH + c] = hh;
-                dxp_s[TR * DSH + lr * DSH + c] = (_Float16)(hs - (float)hh);
+            for (int i = 0; i < RV; ++i) {                  // c < 320: every plane entry, zeros beyond column 299
+                const int c = rv_col(lane, i);
+                if (c < N2P) {
+                    uint2 ph, pm;
+                    split4(make_float4(vv[i].x * sc, vv[i].y * sc, vv[i].z * sc, vv[i].w * sc), ph, pm);
+                    *reinterpret_cast<uint2 *>(dxp_s + lr * DSH + c) = ph;
+                    *reinterpret_cast<uint2 *>(dxp_s + TR * DSH + lr * DSH + c) = pm;
+                }
             }
             if (lane == 0) rsc_s[lr] = inv * (1.f / SWL);
         }
@@ -723,7 +829,11 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
                     dst[u][t][1] = *reinterpret_cast<const f16x8 *>(bh + IMG_T + (size_t)(t * BW_STEPS + g * GU + u) * 512);
                 }
         };
-        load_group(0, bcur);
+        static_assert(GU == GU_B, "the prefetched group is group 0");
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { bcur[u][t][0] = bpre[u][t][0]; bcur[u][t][1] = bpre[u][t][1]; }
 #pragma unroll
         for (int g = 0; g < NGRP; ++g) {
             if (g + 1 < NGRP) load_group(g + 1, bnxt);
@@ -858,6 +968,10 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows_pair(const int n, const fl
     __shared__ float red[2 * NW * TR];
     __shared__ float rsc_s[TR];
     const int nb = (n + TR - 1) / TR;
+    if ((int)blockIdx.x == 2 * nb) {         // the extra workgroup: counters + bias corrections (nothing in this launch reads them)
+        if (threadIdx.x == 0) clock_tick(td);
+        return;
+    }
     KBEGIN(1);
     if ((int)blockIdx.x < nb) {
         bwd_rows_body<true>(n, 1, scale_c, nullptr, q_out, nullptr, nullptr, Wc, sv_c, o_c, td, dx2_s, red, rsc_s, blockIdx.x * TR);
@@ -887,7 +1001,20 @@ struct AdamFused {
     float lr, beta1, beta2, eps, weight_decay, tau;
     int on;
     _Float16 *img_p, *img_t;      // fc2 images of the network / its target that this step keeps current (or nullptr)
+    const float *bias_corr;       // clock_tick()'s {step, beta1, beta2, 1 - beta1^t, 1 - beta2^t} or nullptr
 };
+
+// Adam's bias corrections for step t: from clock_tick()'s buffer when it holds exactly this step and these betas (c = its five
+// floats, loaded by the caller with its other loads), else evaluated here
+__device__ __forceinline__ void adam_bias_corrections(const float beta1, const float beta2, const long long t, const bool have,
+                                                      const float (&c)[5], float &bc1, float &bc2) {
+    if (have && __float_as_int(c[0]) == (int)t && c[1] == beta1 && c[2] == beta2) {
+        bc1 = c[3]; bc2 = c[4];
+    } else {
+        bc1 = (float)(1.0 - pow((double)beta1, (double)t));
+        bc2 = (float)(1.0 - pow((double)beta2, (double)t));
+    }
+}
 
 struct AdamElem { float p, m, v, tg; };
 
@@ -983,14 +1110,22 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
 #ifdef TT_STAMPS
     if (threadIdx.x == 0) g_blk[blockIdx.x][0] = wall_clock64();
 #endif
+    WST(8);
     long long step_count = 0;
-    if (A.on) step_count = *A.step_dev;
+    float bcc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (A.on) {
+        step_count = *A.step_dev;
+        if (A.bias_corr) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) bcc[i] = A.bias_corr[i];
+        }
+    }
     auto bias_corrections = [&](float &bc1, float &sqrt_bc2) __attribute__((always_inline)) {
         bc1 = 1.f; sqrt_bc2 = 1.f;
         if (A.on) {
-            const double t = (double)step_count;
-            bc1 = (float)(1.0 - pow((double)A.beta1, t));
-            sqrt_bc2 = sqrtf((float)(1.0 - pow((double)A.beta2, t)));
+            float bc2;
+            adam_bias_corrections(A.beta1, A.beta2, step_count, A.bias_corr != nullptr, bcc, bc1, bc2);
+            sqrt_bc2 = sqrtf(bc2);
         }
     };
     const int rows_w = (((n + 3) / 4) + 15) / 16 * 16;                  // batch rows per wave, whole k16 steps
@@ -1027,6 +1162,7 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
                     if (!(b < b_hi && cok)) bv[it][ks] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
         }
+        WST(9);
         // the four elements' optimizer state: requested with the operands (the updates below also store through pointers that
         // may alias a later load)
         AdamElem el[4] = {};
@@ -1253,7 +1389,9 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
         float *const outp = reinterpret_cast<float *const *>(&G)[tensor];
         AdamPtrs ad{nullptr, nullptr, nullptr, nullptr};
         if (A.on) ad = AdamPtrs{A.p[tensor], A.m[tensor], A.v[tensor], A.tgt[tensor]};
-        constexpr int RCH = 32;                    // rows in flight per wave: two rounds at 256 rows (these workgroups do little else)
+        // rows in flight per wave: two rounds at 256 rows (these workgroups do little else); four with row factors, which keeps
+        // the launch at <= 168 registers = three workgroups per CU
+        constexpr int RCH = ROWSCALE ? 16 : 32;
         const int rows = (n + 3) / 4, lo = wave * rows, hi = min(n, lo + rows);
         // unconditional loads from clamped addresses (see the dW2 blocks); a quantity without a second operand reads its first
         // one twice (same lines) and multiplies by 1
@@ -1323,13 +1461,19 @@ struct AdamTable {
 
 __global__ __launch_bounds__(256) void k_adam_soft(const AdamTable T, const long long *__restrict__ step_dev,
                                                    const float lr, const float beta1, const float beta2,
-                                                   const float eps, const float weight_decay, const float tau) {
+                                                   const float eps, const float weight_decay, const float tau,
+                                                   const float *__restrict__ bias_corr) {
     int ti = 0;
     while (ti + 1 < T.count && (int)blockIdx.x >= T.block_start[ti + 1]) ++ti;
     const int i = ((int)blockIdx.x - T.block_start[ti]) * 256 + threadIdx.x;
     if (i >= T.numel[ti]) return;
-    const double t = (double)*step_dev;
-    const float bc1 = (float)(1.0 - pow((double)beta1, t)), bc2 = (float)(1.0 - pow((double)beta2, t));
+    float bcc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bias_corr) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) bcc[q] = bias_corr[q];
+    }
+    float bc1, bc2;
+    adam_bias_corrections(beta1, beta2, *step_dev, bias_corr != nullptr, bcc, bc1, bc2);
     float p = T.p[ti][i];
     const float g = fmaf(weight_decay, p, T.g[ti][i]);
     const float m = fmaf(beta1, T.m[ti][i], (1.f - beta1) * g);          // exp_avg.lerp_(grad, 1 - beta1)
@@ -1489,7 +1633,7 @@ static int backward_impl(int n, int critic, int mode, float scale, const float *
             return TT_EINVAL;
         td = TdIn{tdi->z_state, tdi->mu_target, tdi->reward, tdi->done, tw->wa, tw->ba, tw->w3, tw->b3, tdi->gamma,
                   tdi->y_out, tdi->q_out, reinterpret_cast<long long *>(tdi->step_dev),
-                  reinterpret_cast<long long *>(tdi->window_dev)};
+                  reinterpret_cast<long long *>(tdi->window_dev), nullptr, 0.f, 0.f, 0};
     }
     if (!saved->xh1 || !saved->h1 || !saved->xh2 || !saved->h2 || !saved->rstd1 || !saved->rstd2 || !ws->dpre || !ws->dz ||
         !ws->dx2 || !ws->dy1 || !ws->dx1)
@@ -1559,12 +1703,12 @@ int tt_mlp_backward_rows_pair(int n, float scale_critic, const float *q_out, con
     if (!tdi->z_state || !tdi->mu_target || !ok_shape(tw, true) || !tdi->reward || !tdi->done || !tdi->y_out) return TT_EINVAL;
     const TdIn td{tdi->z_state, tdi->mu_target, tdi->reward, tdi->done, tw->wa, tw->ba, tw->w3, tw->b3, tdi->gamma,
                   tdi->y_out, tdi->q_out, reinterpret_cast<long long *>(tdi->step_dev),
-                  reinterpret_cast<long long *>(tdi->window_dev)};
+                  reinterpret_cast<long long *>(tdi->window_dev), tdi->bias_corr_out, tdi->adam_beta1, tdi->adam_beta2, 1};
     const Saved sc{saved_critic->xh1, saved_critic->h1, saved_critic->xh2, saved_critic->h2, saved_critic->rstd1, saved_critic->rstd2};
     const Saved sa{saved_actor->xh1, saved_actor->h1, saved_actor->xh2, saved_actor->h2, saved_actor->rstd1, saved_actor->rstd2};
     const BwdOut oc{ws_critic->dpre, ws_critic->dz, ws_critic->dx2, ws_critic->dy1, ws_critic->dx1};
     const BwdOut oa{ws_actor->dpre, ws_actor->dz, ws_actor->dx2, ws_actor->dy1, ws_actor->dx1};
-    hipLaunchKernelGGL(k_bwd_rows_pair, dim3(2 * ((n + TR - 1) / TR)), dim3(64 * NW), 0, stream, n, scale_critic, q_out,
+    hipLaunchKernelGGL(k_bwd_rows_pair, dim3(2 * ((n + TR - 1) / TR) + 1), dim3(64 * NW), 0, stream, n, scale_critic, q_out,
                        to_weights(critic), sc, oc, td, mu_out, to_weights(actor), sa, oa);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
@@ -1573,7 +1717,8 @@ int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *ac
                             const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const float *row_dq_da, const float *row_mu,
                             float row_scale, int count, float *const *params, float *const *exp_avg, float *const *exp_avg_sq,
                             float *const *targets, const int64_t *step_dev, float lr, float beta1, float beta2, float eps,
-                            float weight_decay, float tau, const tt_fc2_images *images, tt_stream_t stream) {
+                            float weight_decay, float tau, const tt_fc2_images *images, const float *bias_corr,
+                            tt_stream_t stream) {
     if (n <= 0 || !obs || (critic && !action) || !saved_ok(saved) || !ws_ok(ws) || !ok_shape(grads, critic != 0) ||
         ((row_dq_da == nullptr) != (row_mu == nullptr)))
         return TT_EINVAL;
@@ -1587,6 +1732,7 @@ int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *ac
         A.step_dev = reinterpret_cast<const long long *>(step_dev);
         A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.weight_decay = weight_decay; A.tau = tau;
         A.on = 1;
+        A.bias_corr = bias_corr;
         if (images) {
             A.img_p = reinterpret_cast<_Float16 *>(images->net);
             A.img_t = reinterpret_cast<_Float16 *>(images->target);
@@ -1608,7 +1754,7 @@ int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *ac
 int tt_adam_soft_update(int count, float *const *params, const float *const *grads, float *const *exp_avg,
                         float *const *exp_avg_sq, float *const *targets, const int32_t *numel, const int64_t *step_dev,
                         float lr, float beta1, float beta2, float eps, float weight_decay, float tau,
-                        const tt_fc2_images *images, tt_stream_t stream) {
+                        const tt_fc2_images *images, const float *bias_corr, tt_stream_t stream) {
     if (count <= 0 || count > MAXT || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !step_dev) return TT_EINVAL;
     AdamTable T{};
     if (images && (images->net || images->target)) {       // tensors must then be in tt_mlp_weights order: w2 is number 4
@@ -1628,7 +1774,7 @@ int tt_adam_soft_update(int count, float *const *params, const float *const *gra
     }
     T.block_start[count] = blocks;
     hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, stream, T, reinterpret_cast<const long long *>(step_dev), lr,
-                       beta1, beta2, eps, weight_decay, tau);
+                       beta1, beta2, eps, weight_decay, tau, bias_corr);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 

@@ -93,6 +93,8 @@ class FusedLearner:
         self.ws_actor = L.TTMlpBwdWs(**{k: v.data_ptr() for k, v in self.ws_actor_t.items()})
         self.mu_t, self.q_t, self.y, self.q, self.mu, self.q_pi, self.dq_da = (torch.empty(B, **f) for _ in range(7))
         self.step_dev = torch.zeros((), dtype=torch.int64, device=dev)      # learn() calls done (Adam's step count)
+        # Adam's bias corrections of the running step, left by the launch that advances step_dev (tt_td_input.bias_corr_out)
+        self.bias_corr = torch.zeros(8, dtype=torch.float32, device=dev)
         self.z_t = torch.empty((B, 300), **f)          # the target critic's state branch on s' (before the action enters)
         self.grad_sync_critic = self.grad_sync_actor = None
         ga, gc = agent.actor.optimizer.param_groups[0], agent.critic.optimizer.param_groups[0]
@@ -182,7 +184,7 @@ class FusedLearner:
         lr, b1, b2, eps, wd = hyp
         L.check(self.lib.tt_adam_soft_update(st.count, st.a_p, st.a_g, st.a_m, st.a_v, st.a_t, st.a_n, _p(self.step_dev),
                                              lr, b1, b2, eps, wd, tau, C.byref(st.images) if st.images is not None else None,
-                                             self._stream()))
+                                             _p(self.bias_corr), self._stream()))
 
     def enable_data_parallel(self, group=None):
         """Mean of the flat gradient buffers over the ranks at the reference's two optimizer sites (RCCL: one AVG
@@ -230,7 +232,8 @@ class FusedLearner:
                          target_critic=C.pointer(self.w(ag.target_critic)), reward=rewards.data_ptr(),
                          done=done_u8.data_ptr(), gamma=float(ag.gamma), y_out=self.y.data_ptr(),
                          q_out=self.q_t.data_ptr(), step_dev=self.step_dev.data_ptr(),
-                         window_dev=window_dev.data_ptr() if window_dev is not None else None)
+                         window_dev=window_dev.data_ptr() if window_dev is not None else None,
+                         bias_corr_out=self.bias_corr.data_ptr(), adam_beta1=self.hyp_critic[1], adam_beta2=self.hyp_critic[2])
         # ... and, on other workgroups of the same launch, the ACTOR's per-row backward for a unit gradient: it is linear in
         # the row's d(loss)/d(pre-tanh), which needs the updated critic and is applied in phase_b (include/ttenv.h)
         L.check(self.lib.tt_mlp_backward_rows_pair(B, 2.0 / B, _p(self.q), C.byref(self.w(ag.critic)),
@@ -247,7 +250,7 @@ class FusedLearner:
                                                  C.byref(st.gstruct), _p(dq), _p(mu), float(sc), st.count if adam else 0,
                                                  st.a_p, st.a_m, st.a_v, st.a_t, _p(self.step_dev), lr, b1, b2, eps, wd, tau,
                                                  C.byref(st.images) if (adam and st.images is not None) else None,
-                                                 self._stream()))
+                                                 _p(self.bias_corr), self._stream()))
 
     def phase_b(self, states, separate_adam):
         """[critic Adam/soft update when not already applied,] then the actor step through the UPDATED critic

@@ -386,7 +386,15 @@ typedef struct tt_td_input {
     int64_t *step_dev;
     int64_t *window_dev;   /* optional: a second device counter advanced by 1 -- the sampling-window counter of a pipelined
                               loop (tt_ring_sample's k_dev), moved on by the last learn() of a vector step */
+    /* optional (tt_mlp_backward_rows_pair only): the launch that advances *step_dev also leaves Adam's bias corrections of
+     * the NEW step t for the pair (adam_beta1, adam_beta2) in bias_corr_out[0..4] = {t (int32 bits), beta1, beta2,
+     * 1 - beta1^t, 1 - beta2^t}, evaluated once in f64 on a workgroup of its own; the optimizer launches given the same
+     * buffer (tt_mlp_backward_weights / tt_adam_soft_update: bias_corr) use it when step and betas match and otherwise
+     * evaluate the two pow() themselves, in every thread: ~1.1 us per launch (DDPG/networks.py:49-50,133: torch.optim.Adam) */
+    float *bias_corr_out;
+    float adam_beta1, adam_beta2;
 } tt_td_input;
+#define TT_BIAS_CORR_FLOATS 8
 int tt_mlp_backward(int n, int critic, int mode, float scale, const float *obs, const float *action, const float *d_out,
                     const float *out, const float *y, const float *aux, const tt_mlp_weights *w,
                     const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const tt_td_input *td,
@@ -423,7 +431,8 @@ int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *ac
                             const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const float *row_dq_da, const float *row_mu,
                             float row_scale, int count, float *const *params, float *const *exp_avg, float *const *exp_avg_sq,
                             float *const *targets, const int64_t *step_dev, float lr, float beta1, float beta2, float eps,
-                            float weight_decay, float tau, const tt_fc2_images *images /* may be NULL */, tt_stream_t stream);
+                            float weight_decay, float tau, const tt_fc2_images *images /* may be NULL */,
+                            const float *bias_corr /* tt_td_input.bias_corr_out or NULL */, tt_stream_t stream);
 
 /* optimizer.step() of torch.optim.Adam (weight decay folded into the gradient; networks.py:49-50,133) for `count`
  * (<= 12) parameter tensors in one launch, then the soft update of the matching target tensors
@@ -433,7 +442,7 @@ int tt_adam_soft_update(int count, float *const *params, const float *const *gra
                         float *const *exp_avg_sq, float *const *targets, const int32_t *numel, const int64_t *step_dev,
                         float lr, float beta1, float beta2, float eps, float weight_decay, float tau,
                         const tt_fc2_images *images /* may be NULL; tensors in tt_mlp_weights order (w2 = index 4) */,
-                        tt_stream_t stream);
+                        const float *bias_corr /* tt_td_input.bias_corr_out or NULL */, tt_stream_t stream);
 
 /* target = rewards + gamma * critic_value_ with critic_value_[done] = 0 (DDPG_agent.py:89-93); also advances the
  * learn-step counter *step_dev (may be NULL) that tt_adam_soft_update reads. */

@@ -34,7 +34,8 @@ def phases(lib):
     names = ["loads issued -> factors", "factors -> MFMAs done", "pow + partial stores", "barrier", "sums + Adam", "image patch", "end barrier"]
     for k, net in enumerate(("critic", "actor")):
         d = np.diff(w[k, :8]) / 100.0
-        print(f"  k_bwd_weights<{net}> workgroup 0 phases (us):", ", ".join(f"{n} {x:.2f}" for n, x in zip(names, d)))
+        print(f"  k_bwd_weights<{net}> workgroup 0 phases (us): entry -> operand loads issued {(w[k, 9] - w[k, 8]) / 100.0:.2f}, -> Adam state "
+              f"loads issued {(w[k, 0] - w[k, 9]) / 100.0:.2f},", ", ".join(f"{n} {x:.2f}" for n, x in zip(names, d)))
     st = (C.c_ulonglong * 32)()
     lib.tt_debug_stamps(st)
     f = list(st)
@@ -42,7 +43,7 @@ def phases(lib):
         tuple((f[i + 1] - f[i]) / 100 for i in range(4)) + tuple((f[i + 1] - f[i]) / 100 for i in (8, 9, 10))))
 
 
-def report(a, title):
+def report(a, title, lib=None):
     print(title)
     t0 = a[0, :GRID[0], 0].min()
     prev_end = None
