@@ -544,6 +544,11 @@ def main():
             "algorithmic_f32_tflops": useful / (act_ms * 1e-3) / 1e12,
             "algorithmic_frac_of_16bit_peak": useful / (act_ms * 1e-3) / 1e12 / 2500.0,
             "f32_mfma_peak_tflops": 157.3}
+    if ddpg_loop is not None and ddpg_loop.ring_mode:
+        gave_up = ddpg_loop.ring.policy_gave_up()      # (device-memory hand-over of the policy image: include/ttenv.h)
+        assert gave_up == 0, f"a policy launch gave up waiting for the image of step {gave_up - 1}"
+        out["config"]["policy_image_handover"] = ("graph edge" if (os.environ.get("TT_POLICY_EDGE", "flag") == "graph" or
+                                                                    ddpg_loop.updates_per_step > 1) else "device memory (epoch word)")
     if ar_us is not None:
         out["allreduce_us"] = ar_us
     if rank == 0:

@@ -20,6 +20,7 @@
 #include <cstdint>
 
 #include "ttenv.h"
+#include "ttnet_common.h"      // the replay draw (ring_sample_index): k_fwd_multi can make it itself
 
 namespace {
 
@@ -223,7 +224,12 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
                                                const float *__restrict__ action, const Weights &W,
                                                float *__restrict__ out, const Saved &sv, float *__restrict__ dq_da,
                                                float *__restrict__ z_state, float *__restrict__ h1_s,
-                                               float *__restrict__ z_s, const int row0) {
+                                               float *__restrict__ z_s, const int row0,
+                                               const float *__restrict__ obs_row_lane = nullptr,
+                                               const bool act_given = false, const float act_row0 = 0.f,
+                                               const float act_row1 = 0.f) {
+    // obs_row_lane (optional): this lane's observation row for layer 1 (row row0 + (lane & 15)) when the rows are gathered
+    // from a replay ring instead of read from obs [n,23]; act_given / act_row0, 1: the actions of this wave's two rows likewise.
     // h1_s [16][404]: fc1 pre-activations, then the A operand of layer 2; z_s [16][308]: fc2 pre-activations.
     // The two products split the COLUMNS over the 8 waves; everything per row (both LayerNorms, the head) is done by the
     // wave that owns the row (wave w: rows 2w, 2w+1; lanes stride the columns) after ONE hand-over through LDS, with
@@ -251,7 +257,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
 #pragma unroll
         for (int ks = 0; ks < INP / 4; ++ks) {
             const int k = ks * 4 + l4;
-            a[ks] = (k < IN && row0 + l15 < n) ? obs[(size_t)(row0 + l15) * IN + k] : 0.f;
+            a[ks] = (k < IN && row0 + l15 < n) ? (obs_row_lane ? obs_row_lane[k] : obs[(size_t)(row0 + l15) * IN + k]) : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < MT1; ++i) {
@@ -479,7 +485,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
 #pragma unroll
     for (int rr = 0; rr < TR / NW; ++rr) {
         const int row = row0 + wave * (TR / NW) + rr;
-        avs[rr] = (CRITIC && !z_state && row < n) ? action[row] : 0.f;
+        avs[rr] = (CRITIC && !z_state && row < n) ? (act_given ? (rr == 0 ? act_row0 : act_row1) : action[row]) : 0.f;
     }
     const float b3 = W.b3[0];
 #pragma unroll
@@ -581,6 +587,12 @@ struct FwdJob {
 struct FwdJobs {
     FwdJob j[4];
     int n, blocks_per_job;
+    // sampled = 1: the launch makes the replay draw R itself (tt_mlp_forward_multi_sampled) -- every workgroup finds the ring
+    // rows of ITS 16 batch rows (the same Philox draw in every job) and reads s / s' / a straight from the ring; the
+    // workgroups of job write_s also leave s and a, those of job write_s2 leave s', r and done in the draw's batch buffers for
+    // the launches that follow (one launch and one dependent boundary less per learn() than tt_ring_sample + this)
+    int sampled, write_s, write_s2;
+    ttnet::RingSample R;
 };
 __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
     __shared__ __attribute__((aligned(16))) float h1_s[H1S_FLOATS];
@@ -588,8 +600,45 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
     const int job = blockIdx.x / J.blocks_per_job, row0 = (blockIdx.x - job * J.blocks_per_job) * TR;
     const FwdJob &q = J.j[job];
     KBEGIN(0);
-    if (q.critic) fwd_small_body<true>(J.n, q.obs, q.action, q.W, q.out, q.sv, q.dq_da, q.z_state, h1_s, z_s, row0);
-    else fwd_small_body<false>(J.n, q.obs, q.action, q.W, q.out, q.sv, nullptr, nullptr, h1_s, z_s, row0);
+    static_assert(TR / NW == 2, "two rows per wave");
+    const float *orow = nullptr;
+    bool have_act = false;
+    float act_r0 = 0.f, act_r1 = 0.f;
+    if (J.sampled) {
+        const int tid = threadIdx.x, wave = tid >> 6, l15 = tid & 15;
+        const bool from_s = q.obs == J.R.s_out;                  // this job reads s (else s')
+        {
+            const ttnet::RingPick p = ttnet::ring_sample_index(J.R, min(row0 + l15, J.n - 1));
+            orow = from_s ? ttnet::ring_pick_s(J.R, p) : ttnet::ring_pick_s2(J.R, p);
+        }
+        if (q.critic && q.action) {
+            act_r0 = ttnet::ring_pick_a(J.R, ttnet::ring_sample_index(J.R, min(row0 + wave * 2, J.n - 1)));
+            act_r1 = ttnet::ring_pick_a(J.R, ttnet::ring_sample_index(J.R, min(row0 + wave * 2 + 1, J.n - 1)));
+            have_act = true;
+        }
+        if (job == J.write_s || job == J.write_s2) {
+            // the batch rows of this workgroup for the later launches: thread i < 16 x 23 copies one feature
+            const int lr = tid / ttnet::IN, c = tid - lr * ttnet::IN, b = row0 + lr;
+            if (lr < TR && b < J.n) {
+                const ttnet::RingPick p = ttnet::ring_sample_index(J.R, b);
+                if (job == J.write_s) {
+                    J.R.s_out[(size_t)b * ttnet::IN + c] = ttnet::ring_pick_s(J.R, p)[c];
+                    if (c == 0) {
+                        J.R.a_out[b] = ttnet::ring_pick_a(J.R, p);
+                        if (J.R.idx_out) { J.R.idx_out[2 * b] = p.side ? -1 : p.t; J.R.idx_out[2 * b + 1] = p.side ? p.j : p.e; }
+                    }
+                }
+                if (job == J.write_s2) {
+                    J.R.s2_out[(size_t)b * ttnet::IN + c] = ttnet::ring_pick_s2(J.R, p)[c];
+                    if (c == 0) { J.R.r_out[b] = ttnet::ring_pick_r(J.R, p); J.R.d_out[b] = ttnet::ring_pick_d(J.R, p); }
+                }
+            }
+        }
+    }
+    if (q.critic)
+        fwd_small_body<true>(J.n, q.obs, q.action, q.W, q.out, q.sv, q.dq_da, q.z_state, h1_s, z_s, row0, orow, have_act, act_r0, act_r1);
+    else
+        fwd_small_body<false>(J.n, q.obs, q.action, q.W, q.out, q.sv, nullptr, nullptr, h1_s, z_s, row0, orow);
     KEND(0);
 }
 
@@ -1578,16 +1627,29 @@ int tt_mlp_forward_save(int n, int critic, const float *obs, const float *action
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 
-int tt_mlp_forward_multi(int n, int count, const tt_fwd_job *jobs, tt_stream_t stream) {
+static int forward_multi_impl(int n, int count, const tt_fwd_job *jobs, const tt_sample_args *sample, tt_stream_t stream) {
     if (n < 0 || count < 1 || count > 4 || !jobs) return TT_EINVAL;
     if (n == 0) return TT_OK;
     FwdJobs J{};
     J.n = n;
     J.blocks_per_job = (n + TR - 1) / TR;
+    J.write_s = J.write_s2 = -1;
+    if (sample) {
+        if (sample->batch != n) return TT_EINVAL;
+        const int rc = ttnet::make_ring_sample(sample, J.R);
+        if (rc != TT_OK) return rc;
+        J.sampled = 1;
+    }
     for (int i = 0; i < count; ++i) {
         const tt_fwd_job &q = jobs[i];
         const bool critic = q.critic != 0;
         if (!q.obs || !ok_shape(q.w, critic) || (critic && !q.action && !q.z_state) || (!q.out && !q.z_state)) return TT_EINVAL;
+        if (sample) {      // every job reads the draw's s or s'; a critic job's action is the draw's a
+            if (q.obs != sample->s_out && q.obs != sample->s2_out) return TT_EINVAL;
+            if (q.action && (q.action != sample->a_out || q.obs != sample->s_out)) return TT_EINVAL;
+            if (q.obs == sample->s_out && J.write_s < 0) J.write_s = i;
+            if (q.obs == sample->s2_out && J.write_s2 < 0) J.write_s2 = i;
+        }
         Saved sv{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (q.saved) {
             const tt_mlp_saved *p = q.saved;
@@ -1596,8 +1658,18 @@ int tt_mlp_forward_multi(int n, int count, const tt_fwd_job *jobs, tt_stream_t s
         }
         J.j[i] = FwdJob{q.obs, q.action, to_weights(q.w), q.out, sv, q.dq_da, critic ? q.z_state : nullptr, critic ? 1 : 0};
     }
+    if (sample && (J.write_s < 0 || J.write_s2 < 0)) return TT_EINVAL;      // the later launches need all five batch buffers
     hipLaunchKernelGGL(k_fwd_multi, dim3(count * J.blocks_per_job), dim3(64 * NW), 0, stream, J);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+int tt_mlp_forward_multi(int n, int count, const tt_fwd_job *jobs, tt_stream_t stream) {
+    return forward_multi_impl(n, count, jobs, nullptr, stream);
+}
+
+int tt_mlp_forward_multi_sampled(int n, int count, const tt_fwd_job *jobs, const tt_sample_args *sample, tt_stream_t stream) {
+    if (!sample) return TT_EINVAL;
+    return forward_multi_impl(n, count, jobs, sample, stream);
 }
 
 int tt_critic_state_forward(int n, const float *obs, const tt_mlp_weights *w, float *z_state, tt_stream_t stream) {

@@ -301,6 +301,7 @@ static RingCursor to_cursor(const tt_ring_cursor *c) {
 int tt_mlp_split_pack(const tt_mlp_weights *w, int critic, void *ws, int64_t *bump, const tt_ring_cursor *cursor,
                       tt_stream_t stream) {
     if (!ws || !check_ptrs(w, critic != 0)) return TT_EINVAL;
+    if (bump && cursor && bump == cursor->k_dev) return TT_EINVAL;      // (the launch reads the cursor's counter to its end)
     return split_pack(w, critic != 0, ws, reinterpret_cast<long long *>(bump), to_cursor(cursor), stream);
 }
 
@@ -328,17 +329,9 @@ static int make_sample(int batch, int n_envs, int slots, const int64_t *k_dev, c
                        const float *rew, const uint8_t *done, uint64_t seed, int reserve, int lag, const tt_side_buffer *side,
                        float *s_out, float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out,
                        RingSample &R) {
-    if (batch < 0 || n_envs <= 0 || reserve < 0 || lag < 0 || slots < 3 + reserve || !k_dev || !obs || !act || !rew || !done || !s_out ||
-        !a_out || !r_out || !s2_out || !d_out)
-        return TT_EINVAL;
-    SideBuf sb{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    if (side && side->count > 0) {
-        if (!side->obs || !side->act || !side->rew || !side->obs2 || !side->done) return TT_EINVAL;
-        sb = SideBuf{side->obs, side->act, side->rew, side->obs2, side->done, side->count};
-    }
-    R = RingSample{batch, n_envs, slots, reserve, lag, reinterpret_cast<const long long *>(k_dev), obs, act, rew, done, seed, sb,
-                   s_out, a_out, r_out, s2_out, d_out, idx_out};
-    return TT_OK;
+    const tt_sample_args a{batch, n_envs, slots, reserve, k_dev, obs, act, rew, done, seed, side, s_out, a_out, r_out, s2_out,
+                           d_out, idx_out, lag, 0};
+    return make_ring_sample(&a, R);
 }
 
 int tt_actor_act_ring(int n, const tt_ring_view *ring, const tt_mlp_weights *w, float *ou_state, uint64_t seed, uint64_t step,
@@ -352,7 +345,7 @@ int tt_actor_act_ring(int n, const tt_ring_view *ring, const tt_mlp_weights *w, 
     act.step_dev = reinterpret_cast<const long long *>(step_dev);
     act.seed = seed; act.step = step;
     act.decay = 1.0f - theta_dt; act.scale = sigma_sqrt_dt; act.high = high;
-    act.cursor = ring->cursor; act.ring_n = n;
+    act.cursor = ring->cursor; act.ring_n = n; act.ring_slots = ring->slots;
     return launch<false>(n, ring->obs, nullptr, w, nullptr, act, stream);
 }
 

@@ -35,6 +35,7 @@ struct ActArgs {                        // optional fused choose_action epilogue
     // the ring's step counter: its parity picks the pair, and (tt_mlp_weights.split_ws_alt) the policy image.
     int *cursor;
     int ring_n;
+    int ring_slots;                     // slots of the ring (tt_ring_view): the running step's slot numbers follow from *step_dev
 };
 
 // the running step's cursor: the one of the parity of the ring's step counter
@@ -123,7 +124,12 @@ struct RingSample {
     int *idx_out;
 };
 
-__device__ inline void ring_sample_row(const RingSample &R, const int b, const int lane) {
+// where batch row b of a draw comes from: a side tuple j (side = true) or ring transition (slot t, env e), t1 = the slot of s'
+struct RingPick {
+    bool side;
+    int j, t, t1, e;
+};
+__device__ inline RingPick ring_sample_index(const RingSample &R, const int b) {
     const int n_envs = R.n_envs, slots = R.slots;
     // vector steps completed; transitions k-avail .. k-1 are intact.  lag: that many of the newest steps may still be under
     // way on another stream when this draw runs (a loop whose learn() chain runs ahead of its env steps)
@@ -132,35 +138,66 @@ __device__ inline void ring_sample_row(const RingSample &R, const int b, const i
     const long long avail = k < cap ? k : cap;
     uint32_t r[4];
     philox4x32((uint32_t)b, (uint32_t)k, (uint32_t)(k >> 32), 0x5A3Du, (uint32_t)R.seed, (uint32_t)(R.seed >> 32), r);
+    RingPick p{false, 0, 0, 0, 0};
     if (R.side.count > 0) {
         const unsigned long long in_ring = (unsigned long long)avail * (unsigned long long)n_envs;
         const unsigned long long u = ((unsigned long long)r[2] << 32) | r[3];
         if (__umul64hi(u, in_ring + (unsigned long long)R.side.count) < (unsigned long long)R.side.count) {
-            const int j = (int)(((unsigned long long)r[0] * (unsigned long long)R.side.count) >> 32);
-            if (lane < IN) R.s_out[(size_t)b * IN + lane] = R.side.obs[(size_t)j * IN + lane];
-            else if (lane >= 32 && lane < 32 + IN) R.s2_out[(size_t)b * IN + lane - 32] = R.side.obs2[(size_t)j * IN + lane - 32];
-            if (lane == 63) {
-                R.a_out[b] = R.side.act[j];
-                R.r_out[b] = R.side.rew[j];
-                R.d_out[b] = R.side.done[j];
-                if (R.idx_out) { R.idx_out[2 * b] = -1; R.idx_out[2 * b + 1] = j; }
-            }
-            return;
+            p.side = true;
+            p.j = (int)(((unsigned long long)r[0] * (unsigned long long)R.side.count) >> 32);
+            return p;
         }
     }
     const long long back = avail > 0 ? (long long)(((unsigned long long)r[0] * (unsigned long long)avail) >> 32) : 0;
-    const int t = (int)(((k - 1 - back) % slots + slots) % slots), t1 = (t + 1) % slots;
-    const int e = (int)(((unsigned long long)r[1] * (unsigned long long)n_envs) >> 32);
-    const float *src = R.obs + ((size_t)t * n_envs + e) * IN, *src2 = R.obs + ((size_t)t1 * n_envs + e) * IN;
+    p.t = (int)(((k - 1 - back) % slots + slots) % slots);
+    p.t1 = (p.t + 1) % slots;
+    p.e = (int)(((unsigned long long)r[1] * (unsigned long long)n_envs) >> 32);
+    return p;
+}
+// the picked transition's pieces
+__device__ __forceinline__ const float *ring_pick_s(const RingSample &R, const RingPick &p) {
+    return p.side ? R.side.obs + (size_t)p.j * IN : R.obs + ((size_t)p.t * R.n_envs + p.e) * IN;
+}
+__device__ __forceinline__ const float *ring_pick_s2(const RingSample &R, const RingPick &p) {
+    return p.side ? R.side.obs2 + (size_t)p.j * IN : R.obs + ((size_t)p.t1 * R.n_envs + p.e) * IN;
+}
+__device__ __forceinline__ float ring_pick_a(const RingSample &R, const RingPick &p) {
+    return p.side ? R.side.act[p.j] : R.act[(size_t)p.t * R.n_envs + p.e];
+}
+__device__ __forceinline__ float ring_pick_r(const RingSample &R, const RingPick &p) {
+    return p.side ? R.side.rew[p.j] : R.rew[(size_t)p.t * R.n_envs + p.e];
+}
+__device__ __forceinline__ uint8_t ring_pick_d(const RingSample &R, const RingPick &p) {
+    return p.side ? R.side.done[p.j] : R.done[(size_t)p.t * R.n_envs + p.e];
+}
+
+__device__ inline void ring_sample_row(const RingSample &R, const int b, const int lane) {
+    const RingPick p = ring_sample_index(R, b);
+    const float *src = ring_pick_s(R, p), *src2 = ring_pick_s2(R, p);
     if (lane < IN) R.s_out[(size_t)b * IN + lane] = src[lane];
     else if (lane >= 32 && lane < 32 + IN) R.s2_out[(size_t)b * IN + lane - 32] = src2[lane - 32];
     if (lane == 63) {
-        const size_t q = (size_t)t * n_envs + e;
-        R.a_out[b] = R.act[q];
-        R.r_out[b] = R.rew[q];
-        R.d_out[b] = R.done[q];
-        if (R.idx_out) { R.idx_out[2 * b] = t; R.idx_out[2 * b + 1] = e; }
+        R.a_out[b] = ring_pick_a(R, p);
+        R.r_out[b] = ring_pick_r(R, p);
+        R.d_out[b] = ring_pick_d(R, p);
+        if (R.idx_out) { R.idx_out[2 * b] = p.side ? -1 : p.t; R.idx_out[2 * b + 1] = p.side ? p.j : p.e; }
     }
+}
+
+// tt_sample_args -> the kernel-side struct (TT_EINVAL on a missing buffer or an impossible window)
+inline int make_ring_sample(const tt_sample_args *a, RingSample &R) {
+    if (!a || a->batch < 0 || a->n_envs <= 0 || a->reserve < 0 || a->lag < 0 || a->slots < 3 + a->reserve || !a->k_dev || !a->obs ||
+        !a->act || !a->rew || !a->done || !a->s_out || !a->a_out || !a->r_out || !a->s2_out || !a->d_out)
+        return TT_EINVAL;
+    SideBuf sb{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (a->side && a->side->count > 0) {
+        const tt_side_buffer *sd = a->side;
+        if (!sd->obs || !sd->act || !sd->rew || !sd->obs2 || !sd->done) return TT_EINVAL;
+        sb = SideBuf{sd->obs, sd->act, sd->rew, sd->obs2, sd->done, sd->count};
+    }
+    R = RingSample{a->batch, a->n_envs, a->slots, a->reserve, a->lag, reinterpret_cast<const long long *>(a->k_dev), a->obs, a->act,
+                   a->rew, a->done, a->seed, sb, a->s_out, a->a_out, a->r_out, a->s2_out, a->d_out, a->idx_out};
+    return TT_OK;
 }
 
 inline Weights to_weights(const tt_mlp_weights *w) {
@@ -181,6 +218,64 @@ __device__ __forceinline__ void write_cursor(const RingCursor &c) {
     out[1] = (int)((k + 1) % c.slots);
     out[2] = (int)((k + c.slots - 1) % c.slots);
     out[3] = k > 0 ? 1 : 0;
+}
+
+// ---- the hand-over "image + cursor of step k are complete" from the opening pack launch to the policy launch of step k,
+// through device memory instead of a dependency between the two launches.  Words of the cursor buffer (16 ints):
+//   [12], [13]  epoch of the image / cursor pair of even / odd steps: k + 1 once the pack launch of step k has finished;
+//   [14]        workgroups of the running pack launch that have finished (back to 0 by the last one);
+//   [15]        set (to k + 1) by a policy launch that gave up waiting (TT_IMAGE_WAIT_TICKS of the 100 MHz clock).
+// Why: in a loop of two chains of launches (policy + env step | learn()), the one launch-to-launch dependency per step from
+// the learn chain's pack into the step chain's policy cost 9 us of every 92 us vector step on MI355X although it was always
+// satisfied long before (the queue still stops at the wait packet).  Protocol (MI355X_MICROARCH.md, inter-workgroup
+// visibility): producer -- every storing wave waits for its stores, workgroup barrier, ONE lane: agent-scope release, wait,
+// agent-scope add on [14]; the workgroup whose add returns (workgroups - 1) stores the epoch.  Consumer -- one lane polls the
+// epoch (relaxed, agent scope, s_sleep between polls, bounded), then agent-scope acquire, wait, workgroup barrier; only then
+// does the workgroup read cursor or image.  Both sides run on every ring-addressed launch; where the two launches are ordered
+// anyway (same stream) the first poll succeeds.
+constexpr int CUR_EPOCH = 12, CUR_ARRIVED = 14, CUR_GAVE_UP = 15;
+constexpr unsigned long long TT_IMAGE_WAIT_TICKS = 25000000ull;      // 0.25 s
+// (Tried: write-through sc1 stores of image and cursor + each wave's wait, no release fence -- cheaper for the pack launch, but
+// tests/test_distributed.py::test_two_rank_loop_graphs_match_eager then saw a stale image on a plain kernel-to-kernel
+// boundary: kept to plain stores + ONE agent-scope release per workgroup.)
+__device__ __forceinline__ void publish_image(const RingCursor &c, const int workgroups) {      // every thread of the block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && c.cursor) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the compiler may drop its own wait behind the release)
+        const int before = __hip_atomic_fetch_add(c.cursor + CUR_ARRIVED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == workgroups - 1) {
+            const long long k = *c.k_dev;
+            __hip_atomic_store(c.cursor + CUR_ARRIVED, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c.cursor + CUR_EPOCH + (int)(k & 1), (int)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+__device__ __forceinline__ void await_image(int *cursor, const long long *step_dev) {             // every thread of the block
+    if (!cursor) return;
+    if (threadIdx.x == 0) {
+        const long long k = *step_dev;
+        const int want = (int)(k + 1);
+        const int *flag = cursor + CUR_EPOCH + (int)(k & 1);
+        // Fast path (what a loop in step sees): the epoch is already there.  It was then published before this launch began,
+        // whose own start invalidated this CU's caches, and nothing of the image has been read since: no acquire is needed on
+        // top of the launch's (a fence here costs ~1.7 us on the critical path of every policy launch).
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+                __builtin_amdgcn_s_sleep(4);
+                if (wall_clock64() - t0 > TT_IMAGE_WAIT_TICKS) {      // never hang: leave a mark the host checks, and go on
+                    __hip_atomic_store(cursor + CUR_GAVE_UP, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    asm volatile("" ::: "memory");
+    __syncthreads();
 }
 
 // csrc/ttnet_split.hip

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void k_split_pack(const Weights W, const bool 
                                                     unsigned char *__restrict__ ws_alt, long long *__restrict__ bump,
                                                     const RingCursor cur) {
     split_pack_body(W, critic, ws, ws_alt, bump, cur, blockIdx.x * 256 + threadIdx.x);
+    publish_image(cur, PACK_BLOCKS);
 }
 
 // What opens a pipelined vector step, in ONE launch (two small kernels would each cost their ~4 us of launch and a
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256) void k_pack_and_sample(const Weights W, const 
                                                          const RingCursor cur) {
     if ((int)blockIdx.x < PACK_BLOCKS) {
         split_pack_body(W, critic, ws, ws_alt, nullptr, cur, blockIdx.x * 256 + threadIdx.x);
+        publish_image(cur, PACK_BLOCKS);
         return;
     }
     const int b = ((int)blockIdx.x - PACK_BLOCKS) * 4 + (threadIdx.x >> 6);
@@ -232,13 +234,16 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     LB0.b0 = (lds_b *)lds_raw + lane * 16;
     LB0.b1 = LB0.b0 + 65536;
     LB0.b2 = LB0.b0 + 131072;
-    // ring addressing: the image of the running step's parity (the other one may be being written for the next step), and
-    // the first workgroup leaves the running step's cursor where the env step reads it
-    const bool odd = act.cursor && (*act.step_dev & 1);
-    const unsigned char *wsl = (odd && ws_alt) ? ws_alt : ws;
-    if (act.cursor && tile0 == 0 && blockIdx.x == 0 && tid < 4) act.cursor[tid] = cursor_of(act)[tid];
-    const float *obs_base = resolve_obs(act, obs);
-
+    // ring addressing: the running step's slots follow from the ring's step counter (the same numbers the opening pack launch
+    // leaves in the cursor buffer); the first workgroup leaves them where the env step reads them.  The IMAGE of this step
+    // (that of the step's parity: the other one may be being written for the next step) comes from the opening pack launch,
+    // which need not be ordered before this launch: await_image (ttnet_common.h) -- behind the first tile's observation loads,
+    // which do not depend on it.
+    const long long kstep = act.cursor ? *act.step_dev : 0;
+    const bool odd = act.cursor && (kstep & 1);
+    const bool local = act.cursor && act.ring_slots > 0;
+    const int slot_t = local ? (int)(kstep % act.ring_slots) : 0;
+    const float *obs_base = local ? obs + (size_t)slot_t * act.ring_n * IN : obs;      // (re-read from the cursor below when !local)
     // LDS is filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = one 1 KB piece per wave-instruction, no
     // staging registers).  The statements are inline asm, so hipcc neither counts them nor drains them at a barrier:
     // each wave retires its own pieces with an s_waitcnt vmcnt before the barrier that precedes their first read.
@@ -285,7 +290,18 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     // its own count), then packed fc1 + the per-neuron vectors, then k16 steps 0 and 1 of fc2 by DMA
     int tile = tile0 + (int)blockIdx.x;
     if (tile >= tile_end) return;
-    load_obs(tile);
+    if (!act.cursor || local) load_obs(tile);
+    await_image(act.cursor, act.step_dev);
+    const unsigned char *wsl = (odd && ws_alt) ? ws_alt : ws;
+    if (act.cursor && !local) {          // (a caller that gave no slot count: the cursor the pack launch wrote)
+        obs_base = resolve_obs(act, obs);
+        load_obs(tile);
+    }
+    if (act.cursor && tile0 == 0 && blockIdx.x == 0 && tid < 4) {
+        const int sl = act.ring_slots;
+        act.cursor[tid] = !local ? cursor_of(act)[tid]
+                                 : (tid == 0 ? slot_t : tid == 1 ? (int)((kstep + 1) % sl) : tid == 2 ? (int)((kstep + sl - 1) % sl) : (kstep > 0 ? 1 : 0));
+    }
     issue_fc1(wsl, ldsw_w1_0);
 #pragma unroll
     for (int i = 0; i < VEC_PIECES / 4; ++i)

@@ -204,8 +204,10 @@ class FusedLearner:
 
     # learn() in the three pieces the two gradient all-reduces cut it into (each piece is pure kernel launches on the
     # current stream, so a data-parallel loop can capture each as a hipGraph and keep only the collectives eager)
-    def phase_a(self, states, actions, rewards, states_, done_u8, fuse_adam, window_dev=None):
-        """Forwards, TD target, critic backward (+ the critic's Adam/soft update in the same launch when fuse_adam)."""
+    def phase_a(self, states, actions, rewards, states_, done_u8, fuse_adam, window_dev=None, sample=None):
+        """Forwards, TD target, critic backward (+ the critic's Adam/soft update in the same launch when fuse_adam).
+        sample: a tt_sample_args (TrajectoryRing.sample_args) whose batch buffers ARE the five tensors given -- the forward
+        launch then makes the replay draw itself (tt_mlp_forward_multi_sampled) instead of reading a batch drawn before."""
         ag, B = self.agent, self.B
         self._fresh()
         # DDPG_agent.py:85-93 and :87, :101.  Only the target critic's LAST step needs the target actor's action (it enters
@@ -225,7 +227,11 @@ class FusedLearner:
             jobs[j].w, jobs[j].out = C.pointer(self.w(net)), ptr(out)
             jobs[j].saved = C.pointer(saved) if saved is not None else None
             jobs[j].dq_da, jobs[j].z_state = None, ptr(zst)
-        L.check(self.lib.tt_mlp_forward_multi(B, 4, jobs, self._stream()))
+        if sample is not None:
+            assert (sample.s_out, sample.a_out, sample.s2_out) == (states.data_ptr(), actions.data_ptr(), states_.data_ptr())
+            L.check(self.lib.tt_mlp_forward_multi_sampled(B, 4, jobs, C.byref(sample), self._stream()))
+        else:
+            L.check(self.lib.tt_mlp_forward_multi(B, 4, jobs, self._stream()))
         # critic step (DDPG_agent.py:95-98); its backward launch first finishes q'(s', mu'(s')) and the TD target for its
         # rows (tt_td_input: what tt_critic_head_td does as a launch of its own)
         td = L.TTTdInput(z_state=self.z_t.data_ptr(), mu_target=self.mu_t.data_ptr(),
@@ -266,12 +272,13 @@ class FusedLearner:
     def phase_c(self):
         self._adam(self.actor, self.hyp_actor, self.agent.tau)
 
-    def learn_batch(self, states, actions, rewards, states_, done_u8, window_dev=None):
+    def learn_batch(self, states, actions, rewards, states_, done_u8, window_dev=None, sample=None):
         """states, states_ [B,23] f32; actions [B,1] f32; rewards [B] f32; done_u8 [B] uint8 -- all contiguous.
-        window_dev: device int64 advanced by the critic's backward launch (a pipelined loop's sampling window)."""
+        window_dev: device int64 advanced by the critic's backward launch (a pipelined loop's sampling window).
+        sample: see phase_a (the five tensors are then the draw's batch buffers, filled by learn()'s first launch)."""
         assert states.shape[0] == self.B and done_u8.dtype == torch.uint8
         dp = self.grad_sync_critic is not None
-        self.phase_a(states, actions, rewards, states_, done_u8, fuse_adam=not dp, window_dev=window_dev)
+        self.phase_a(states, actions, rewards, states_, done_u8, fuse_adam=not dp, window_dev=window_dev, sample=sample)
         if dp:
             self.grad_sync_critic()
         self.phase_b(states, separate_adam=dp)

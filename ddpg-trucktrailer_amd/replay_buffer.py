@@ -74,7 +74,8 @@ class TrajectoryRing:
         # {t, t+1, t-1, t > 0}: ring slots of the running vector step, written on the device by the step's opening launch
         # (include/ttenv.h: tt_ring_view / tt_ring_cursor) so that captured launches need no per-position pointers
         # [4..7] / [8..11]: the cursors {t, t+1, t-1, t > 0} of even / odd steps, [0..3]: the running step's (include/ttenv.h)
-        self.cursor_dev = torch.zeros(12, dtype=torch.int32, device=device)
+        # ring cursors [0..11] + the image hand-over words [12..15] (include/ttenv.h: TT_CURSOR_INTS)
+        self.cursor_dev = torch.zeros(16, dtype=torch.int32, device=device)
 
     def attach(self, env):
         """Let the env's step kernel advance k_dev (tt_env_set_step_counter): one launch less per vector step.  From
@@ -160,6 +161,12 @@ class TrajectoryRing:
             self.side_epoch += 1
         self.k = int(sd["k"])               # the counters come back whether or not the contents did
         self.k_dev.fill_(self.k)
+        self.cursor_dev.zero_()             # image epochs are step numbers: a counter set back must not find newer ones
+
+    def policy_gave_up(self):
+        """Step number + 1 at which a policy launch stopped waiting for its image (include/ttenv.h: TT_CURSOR_GAVE_UP), 0 = never.
+        Synchronises."""
+        return int(self.cursor_dev[15].item())
 
     def view(self):
         from ddpg_trucktrailer_amd import _lib as L

@@ -174,14 +174,24 @@ class DDPGRollout:
         return (self.seed + u * _SEED_STRIDE) & (2 ** 64 - 1)
 
     def _learn_once(self, u=0, presampled=False):
+        sample = None
         if presampled:         # the step's opening launch already drew this batch into the ring's buffers
+            s, a, r, s2, d = self.ring._batch_bufs(self.batch_size)[:5]
+        elif self.learner is not None and self.device.type == "cuda":
+            # the fused learner's first launch makes the draw itself (tt_mlp_forward_multi_sampled): the same draw as
+            # _sample(u), one launch less per update
+            if self.pipeline:
+                sample = self.ring.sample_args(self.batch_size, seed=self._sample_key(u), k_dev=self.k_pipe_dev,
+                                               reserve=_PIPE_RESERVE, lag=_PIPE_LAG)
+            else:
+                sample = self.ring.sample_args(self.batch_size, seed=self._sample_key(u))
             s, a, r, s2, d = self.ring._batch_bufs(self.batch_size)[:5]
         else:
             s, a, r, s2, d = self._sample(u)
         if self.learner is not None:
             # (pipelined order) the last update of a vector step moves the sampling window on
             last = self.pipeline and u == self.updates_per_step - 1
-            self.learner.learn_batch(s, a, r, s2, d, window_dev=self.k_pipe_dev if last else None)   # raw uint8 done flags
+            self.learner.learn_batch(s, a, r, s2, d, window_dev=self.k_pipe_dev if last else None, sample=sample)   # raw uint8 done flags
         else:
             self.agent.learn_batch(s, a, r, s2, d)
 
@@ -329,7 +339,7 @@ class DDPGRollout:
         """`steps` vector steps in the pipelined order as TWO chains that never join inside the graph:
             B (side stream):  [opening launch: image + cursor + batch] learn()   [opening launch] learn()   ...
             A (this stream):            policy, env step                                policy, env step     ...
-        with one edge each way per step: A(t) waits for the opening launch of step t (its image and cursor), and the opening
+        with one hand-over each way per step: A(t) waits for the opening launch of step t (its image and cursor), and the opening
         launch of step t waits for the env step of step t-2 -- not t-1: the batch of step t holds transitions up to step t-2
         (_PIPE_LAG) and the image / cursor of step t go to the buffers of t's parity, so the opening launch and learn() of
         step t may run beside the policy and env launches of step t-1.  A common join per step put two cross-queue
@@ -337,15 +347,25 @@ class DDPGRollout:
         cur, side = torch.cuda.current_stream(self.device), self._pipe_side
         side.wait_stream(cur)
         stepped = []
+        # A(t) after the opening launch of step t: through DEVICE MEMORY (the pack launch publishes the step's image epoch,
+        # the policy launch waits for it: include/ttenv.h, "image hand-over"), not through a graph edge -- the queue stopped
+        # 9 us per step at that edge's wait packet although the image had always been ready for ~60 us.
+        # TT_POLICY_EDGE=graph puts the edge back (runs under a tool that serialises kernels, e.g. rocprofv3 --pmc: a policy
+        # launch waiting for a pack launch queued BEHIND it would only leave by its 0.25 s limit).
+        # With several updates per step the policy waits for milliseconds: a waiting policy launch would sit on its 171 CUs all
+        # that time (learn() 5 us per update slower beside it), so there the launch is held back by the edge.
+        edge = os.environ.get("TT_POLICY_EDGE", "flag") == "graph" or self.updates_per_step > 1
         for t in range(steps):
             with torch.cuda.stream(side):
                 if t >= 2:
                     side.wait_event(stepped[t - 2])
                 self._open_step(True)
-                opened = torch.cuda.Event()
-                opened.record(side)
+                if edge:
+                    opened = torch.cuda.Event()
+                    opened.record(side)
                 self._learn_all(presampled=True)
-            cur.wait_event(opened)
+            if edge:
+                cur.wait_event(opened)
             self._act_and_step()
             ev = torch.cuda.Event()
             ev.record(cur)

@@ -163,7 +163,7 @@ int tt_env_step(tt_env *env, const float *action, float *obs, float *reward, uin
  * tt_ring_cursor of tt_mlp_split_pack[_and_sample]).  Launches that take a view read / write the step's slots through the
  * cursor instead of through per-slot pointers, so ONE captured hipGraph serves every ring position. */
 typedef struct tt_ring_view {
-    int32_t *cursor;        /* [12] device: [4..7] / [8..11] the cursors of even / odd steps (written by the opening launch of
+    int32_t *cursor;        /* [16] device ([12..15]: the image hand-over words, below): [4..7] / [8..11] the cursors of even / odd steps (written by the opening launch of
                                the step), [0..3] the running step's copy, left by tt_actor_act_ring for tt_env_step_ring */
     float *obs, *act, *rew;
     uint8_t *done;
@@ -172,8 +172,16 @@ typedef struct tt_ring_view {
 typedef struct tt_ring_cursor {
     const int64_t *k_dev;   /* vector steps completed (tt_env_set_step_counter); nothing may advance it beside the launch */
     int32_t slots, reserved_;
-    int32_t *cursor;        /* [12] device (tt_ring_view): the launch writes the four numbers of step *k_dev at [4 + 4 (k & 1)] */
+    int32_t *cursor;        /* [16] device (tt_ring_view): the launch writes the four numbers of step *k_dev at [4 + 4 (k & 1)] */
 } tt_ring_cursor;
+/* Image hand-over (cursor[12..15], zero-initialised by the caller, re-zeroed when *k_dev is set back): a pack launch given a
+ * cursor ends by publishing "cursor and image of step k = *k_dev are complete" as cursor[12 + (k & 1)] = k + 1 (release,
+ * device scope), and tt_actor_act_ring begins by waiting for cursor[12 + (k & 1)] >= k + 1 with k = its *step_dev (bounded:
+ * after 0.25 s it sets cursor[15] = k + 1 and goes on -- TT_CURSOR_GAVE_UP; a caller that lets the two launches run
+ * unordered checks that word).  The two launches of a step therefore need NO stream / graph dependency between them; the
+ * pack launch of step k + 2, which overwrites the same image, must still be ordered behind the policy launch of step k. */
+#define TT_CURSOR_INTS 16
+#define TT_CURSOR_GAVE_UP 15
 /* tt_env_step with obs -> ring slot t+1, reward and done -> slot t (env.step of the vector loop, trainv2.py:520-525). */
 int tt_env_step_ring(tt_env *env, const float *action, const tt_ring_view *ring, int auto_reset, tt_stream_t stream);
 
@@ -352,6 +360,12 @@ typedef struct tt_fwd_job {
     float *dq_da, *z_state;
 } tt_fwd_job;
 int tt_mlp_forward_multi(int n, int count, const tt_fwd_job *jobs, tt_stream_t stream);
+/* The same with the replay draw of ReplayBuffer.sample_buffer (DDPG/replay_buffer.py:23-34) made BY this launch: `sample`
+ * are tt_ring_sample's arguments (batch = n); every job's obs must be sample->s_out or sample->s2_out and a critic job's
+ * action sample->a_out -- the workgroups read those rows straight from the ring, and the five batch buffers are filled on
+ * the way for the launches that follow (at least one job on s and one on s').  One launch and one dependent launch boundary
+ * less per learn() than tt_ring_sample followed by tt_mlp_forward_multi; the same draw, bit for bit. */
+int tt_mlp_forward_multi_sampled(int n, int count, const tt_fwd_job *jobs, const tt_sample_args *sample, tt_stream_t stream);
 
 /* The target critic in two pieces, so that its state branch can run NEXT TO the target actor that produces its action:
  * tt_critic_state_forward: z_state [n,300] = bn2(fc2(relu(bn1(fc1(s))))) (networks.py:55-61, before the action enters);

@@ -344,12 +344,40 @@ def test_whole_config3_loop_at_bench_size(gpu_device, graph_steps, steps):
         assert torch.isfinite(flat).all() and not torch.equal(flat, w0)
         assert torch.isfinite(loop.ring.rew[:steps]).all() and int(loop.learner.step_dev.item()) == steps - 2
         assert int(loop.ring.k_dev.item()) == steps and int(loop.k_pipe_dev.item()) == steps
+        assert loop.ring.policy_gave_up() == 0          # no policy launch ran out of patience waiting for its image
         flats.append((flat.clone(), loop.ring.obs[:steps + 1].clone(), loop.ring.act[:steps].clone(), loop.env.state.clone(),
                       loop.noise.x.clone()))
         env.close()
         del loop
     for x, y in zip(*flats):
         assert torch.equal(x, y)
+
+
+def test_image_handover_through_device_memory_over_many_steps(gpu_device):
+    """The policy launch of a step takes its image and cursor from the step's opening pack launch with NO dependency between the
+    two launches in the captured graphs (include/ttenv.h, "image hand-over": epoch words next to the cursor; the learn chain
+    runs ~60 us ahead, under load, on other CUs and XCDs than the readers, which re-read the same two image buffers every other
+    step -- warm in their L1 / L2).  1500 graph-replayed steps at the bench size == 1500 eager steps (where the two launches
+    are ordered on one stream), bit for bit: one stale fragment anywhere in 1500 x 512 tile forwards would move an action, and
+    with it the env state, the ring and every weight after it."""
+    import torch
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    n, steps = 65536, 1500
+    outs = []
+    for g in (20, 0):
+        env = TruckTrailerVecEnv(n)
+        env.reset(seed=3)
+        loop = DDPGRollout(env, batch_size=256, replay_slots=16, seed=3, graph_steps=g)
+        loop.run(steps)
+        torch.cuda.synchronize()
+        assert loop.ring.policy_gave_up() == 0
+        outs.append((_loop_flat(loop).clone(), loop.env.state.clone(), loop.noise.x.clone(), loop.ring.act.clone(), loop.ring.rew.clone()))
+        env.close()
+        del loop
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert torch.isfinite(outs[0][0]).all()
 
 
 @pytest.mark.parametrize("pipeline", [True, False])
