@@ -354,7 +354,9 @@ class DDPGRollout:
         # launch waiting for a pack launch queued BEHIND it would only leave by its 0.25 s limit).
         # With several updates per step the policy waits for milliseconds: a waiting policy launch would sit on its 171 CUs all
         # that time (learn() 5 us per update slower beside it), so there the launch is held back by the edge.
-        edge = os.environ.get("TT_POLICY_EDGE", "flag") == "graph" or self.updates_per_step > 1
+        # Data-parallel ranks keep the edge as well: that path has never run on more than one GPU, and a collective that takes
+        # long inside the learn chain must never meet a policy launch with a time limit.
+        edge = os.environ.get("TT_POLICY_EDGE", "flag") == "graph" or self.updates_per_step > 1 or self.dp
         for t in range(steps):
             with torch.cuda.stream(side):
                 if t >= 2:
