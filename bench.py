@@ -547,9 +547,7 @@ def main():
     if ddpg_loop is not None and ddpg_loop.ring_mode:
         gave_up = ddpg_loop.ring.policy_gave_up()      # (device-memory hand-over of the policy image: include/ttenv.h)
         assert gave_up == 0, f"a policy launch gave up waiting for the image of step {gave_up - 1}"
-        out["config"]["policy_image_handover"] = ("graph edge" if (os.environ.get("TT_POLICY_EDGE", "flag") == "graph" or
-                                                                    ddpg_loop.updates_per_step > 1 or ddpg_loop.dp)
-                                                   else "device memory (epoch word)")
+        out["config"]["policy_image_handover"] = ("graph edge" if ddpg_loop.policy_edge() == "graph" else "device memory (epoch word)")
     if ar_us is not None:
         out["allreduce_us"] = ar_us
     if rank == 0:

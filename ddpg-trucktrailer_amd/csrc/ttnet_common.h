@@ -262,9 +262,11 @@ __device__ __forceinline__ void await_image(int *cursor, const long long *step_d
         // whose own start invalidated this CU's caches, and nothing of the image has been read since: no acquire is needed on
         // top of the launch's (a fence here costs ~1.7 us on the critical path of every policy launch).
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+            // (one poll per ~3 us and workgroup: 171 workgroups polling one word every 0.1 us slowed the very launches they
+            // were waiting for -- seen under rocprofv3's kernel trace, where the learn chain falls behind: 224 us per policy launch)
             const unsigned long long t0 = wall_clock64();
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(127);
                 if (wall_clock64() - t0 > TT_IMAGE_WAIT_TICKS) {      // never hang: leave a mark the host checks, and go on
                     __hip_atomic_store(cursor + CUR_GAVE_UP, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;

@@ -244,6 +244,18 @@ class DDPGRollout:
         else:
             fused.pack(self.agent.actor, 0, cursor=self.ring.cursor())
 
+    def policy_edge(self):
+        """How the policy launch of a captured step learns that its image is complete: "flag" (device memory, the default) or
+        "graph" (a graph edge from the opening launch) -- with several updates per step, for data-parallel ranks, on request
+        (TT_POLICY_EDGE=graph) and under rocprofv3: a tool that intercepts every dispatch keeps the learn chain ~45 us per
+        launch behind, the policy launch then spends its life waiting (189 us per launch in a kernel trace) and the trace says
+        nothing about the loop; with --pmc (kernels serialised) a waiting launch would only leave by its time limit."""
+        if os.environ.get("TT_POLICY_EDGE", "flag") == "graph" or self.updates_per_step > 1 or self.dp:
+            return "graph"
+        if os.environ.get("TT_POLICY_EDGE") != "flag" and any(k.startswith("ROCPROF") or k == "ROCP_TOOL_LIBRARIES" for k in os.environ):
+            return "graph"
+        return "flag"
+
     def policy_launch(self):
         """The policy launch of the running step alone (ring mode; after _open_step): bench.py times it."""
         w = fused.packed_weights_of(self.agent.actor, 0, self.policy_workgroups if self.pipeline else 0,
@@ -356,7 +368,7 @@ class DDPGRollout:
         # that time (learn() 5 us per update slower beside it), so there the launch is held back by the edge.
         # Data-parallel ranks keep the edge as well: that path has never run on more than one GPU, and a collective that takes
         # long inside the learn chain must never meet a policy launch with a time limit.
-        edge = os.environ.get("TT_POLICY_EDGE", "flag") == "graph" or self.updates_per_step > 1 or self.dp
+        edge = self.policy_edge() == "graph"
         for t in range(steps):
             with torch.cuda.stream(side):
                 if t >= 2:
