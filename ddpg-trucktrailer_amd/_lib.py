@@ -81,6 +81,10 @@ class TTSampleArgs(C.Structure):
                 ("reserved_", C.c_int32)]
 
 
+class TTImageJob(C.Structure):
+    _fields_ = [("actor", C.POINTER(TTMlpWeights)), ("cursor", C.POINTER(TTRingCursor))]
+
+
 class TTMlpBwdWs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dpre", "dz", "dx2", "dy1", "dx1")]
 
@@ -128,7 +132,7 @@ _SIGNATURES = {
     "tt_critic_forward": (C.c_int, [_I, _P, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_mlp_forward_save": (C.c_int, [_I, _I, _P, _P, C.POINTER(TTMlpWeights), _P, C.POINTER(TTMlpSaved), _P, _P]),
     "tt_mlp_forward_multi": (C.c_int, [_I, _I, C.POINTER(TTFwdJob), _P]),
-    "tt_mlp_forward_multi_sampled": (C.c_int, [_I, _I, C.POINTER(TTFwdJob), C.POINTER(TTSampleArgs), _P]),
+    "tt_mlp_forward_multi_sampled": (C.c_int, [_I, _I, C.POINTER(TTFwdJob), C.POINTER(TTSampleArgs), _P, _P]),
     "tt_critic_state_forward": (C.c_int, [_I, _P, C.POINTER(TTMlpWeights), _P, _P]),
     "tt_critic_head_td": (C.c_int, [_I, _P, _P, C.POINTER(TTMlpWeights), _P, _P, C.c_float, _P, _P, _P, _P]),
     "tt_mlp_backward": (C.c_int, [_I, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, C.POINTER(TTMlpWeights),
@@ -140,7 +144,7 @@ _SIGNATURES = {
                                        C.POINTER(TTTdInput), _P]),
     "tt_mlp_backward_rows_pair": (C.c_int, [_I, C.c_float, _P, C.POINTER(TTMlpWeights), C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs),
                                             C.POINTER(TTTdInput), _P, C.POINTER(TTMlpWeights), C.POINTER(TTMlpSaved),
-                                            C.POINTER(TTMlpBwdWs), _P]),
+                                            C.POINTER(TTMlpBwdWs), C.POINTER(TTImageJob), _P]),
     "tt_mlp_backward_weights": (C.c_int, [_I, _I, _P, _P, C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights),
                                           _P, _P, C.c_float, _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                           C.c_float, C.c_float, C.POINTER(TTFc2Images), _P, _P]),

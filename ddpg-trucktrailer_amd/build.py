@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", f) for f in ("ttenv.hip", "ttnet.hip", "ttnet_split.hip", "ttlearn.hip")]
-HDR = [os.path.join(ROOT, "include", "ttenv.h"), os.path.join(HERE, "csrc", "ttnet_common.h")]
+HDR = [os.path.join(ROOT, "include", "ttenv.h"), os.path.join(HERE, "csrc", "ttnet_common.h"), os.path.join(HERE, "csrc", "ttnet_pack.h")]
 LIB = os.path.join(HERE, "libttenv.so")
 
 

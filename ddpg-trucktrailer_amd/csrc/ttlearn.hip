@@ -21,6 +21,7 @@
 
 #include "ttenv.h"
 #include "ttnet_common.h"      // the replay draw (ring_sample_index): k_fwd_multi can make it itself
+#include "ttnet_pack.h"        // the policy image (split_pack_body): k_bwd_rows_pair can carry its pack
 
 namespace {
 
@@ -593,6 +594,7 @@ struct FwdJobs {
     // the launches that follow (one launch and one dependent boundary less per learn() than tt_ring_sample + this)
     int sampled, write_s, write_s2;
     ttnet::RingSample R;
+    long long *k_snapshot;       // (sampled) *R.k_dev as this launch saw it, for a later launch (tt_image_job) or nullptr
 };
 __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
     __shared__ __attribute__((aligned(16))) float h1_s[H1S_FLOATS];
@@ -606,6 +608,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
     float act_r0 = 0.f, act_r1 = 0.f;
     if (J.sampled) {
         const int tid = threadIdx.x, wave = tid >> 6, l15 = tid & 15;
+        if (J.k_snapshot && blockIdx.x == 0 && tid == 0) *J.k_snapshot = *J.R.k_dev;
         const bool from_s = q.obs == J.R.s_out;                  // this job reads s (else s')
         {
             const ttnet::RingPick p = ttnet::ring_sample_index(J.R, min(row0 + l15, J.n - 1));
@@ -1009,16 +1012,31 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows(const int n, const int mod
 // LayerNorm backwards, dH1 = dX2 * W2) only needs what the forward saved.  So that part runs HERE, beside the critic's
 // backward, for a unit gradient, and k_bwd_weights multiplies row b by the real number once the critic has been updated and
 // dQ/da is known: the actor's backward is off the chain's critical path.
+// Optional rider: the pack of a vector step's policy image (csrc/ttnet_pack.h) on IMAGE_WGS further workgroups of this launch.
+struct ImageJob {
+    ttnet::Weights W;
+    unsigned char *ws, *ws_alt;
+    ttnet::RingCursor cur;
+    int on;
+};
+constexpr int IMAGE_WGS = (ttnet::PACK_THREADS + 64 * NW - 1) / (64 * NW);
+
 __global__ __launch_bounds__(64 * NW) void k_bwd_rows_pair(const int n, const float scale_c, const float *__restrict__ q_out,
                                                            const Weights Wc, const Saved sv_c, const BwdOut o_c, const TdIn td,
                                                            const float *__restrict__ mu_out, const Weights Wa, const Saved sv_a,
-                                                           const BwdOut o_a) {
+                                                           const BwdOut o_a, const ImageJob img) {
     __shared__ __attribute__((aligned(16))) float dx2_s[DXS_FLOATS];
     __shared__ float red[2 * NW * TR];
     __shared__ float rsc_s[TR];
     const int nb = (n + TR - 1) / TR;
     if ((int)blockIdx.x == 2 * nb) {         // the extra workgroup: counters + bias corrections (nothing in this launch reads them)
         if (threadIdx.x == 0) clock_tick(td);
+        return;
+    }
+    if ((int)blockIdx.x > 2 * nb) {          // the image's workgroups (they read a SNAPSHOT of the step number: see ImageJob)
+        ttnet::split_pack_body(img.W, false, img.ws, img.ws_alt, nullptr, img.cur,
+                               ((int)blockIdx.x - 2 * nb - 1) * (64 * NW) + (int)threadIdx.x);
+        ttnet::publish_image(img.cur, IMAGE_WGS);
         return;
     }
     KBEGIN(1);
@@ -1627,7 +1645,8 @@ int tt_mlp_forward_save(int n, int critic, const float *obs, const float *action
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 
-static int forward_multi_impl(int n, int count, const tt_fwd_job *jobs, const tt_sample_args *sample, tt_stream_t stream) {
+static int forward_multi_impl(int n, int count, const tt_fwd_job *jobs, const tt_sample_args *sample, int64_t *k_snapshot,
+                              tt_stream_t stream) {
     if (n < 0 || count < 1 || count > 4 || !jobs) return TT_EINVAL;
     if (n == 0) return TT_OK;
     FwdJobs J{};
@@ -1639,6 +1658,7 @@ static int forward_multi_impl(int n, int count, const tt_fwd_job *jobs, const tt
         const int rc = ttnet::make_ring_sample(sample, J.R);
         if (rc != TT_OK) return rc;
         J.sampled = 1;
+        J.k_snapshot = reinterpret_cast<long long *>(k_snapshot);
     }
     for (int i = 0; i < count; ++i) {
         const tt_fwd_job &q = jobs[i];
@@ -1664,12 +1684,13 @@ static int forward_multi_impl(int n, int count, const tt_fwd_job *jobs, const tt
 }
 
 int tt_mlp_forward_multi(int n, int count, const tt_fwd_job *jobs, tt_stream_t stream) {
-    return forward_multi_impl(n, count, jobs, nullptr, stream);
+    return forward_multi_impl(n, count, jobs, nullptr, nullptr, stream);
 }
 
-int tt_mlp_forward_multi_sampled(int n, int count, const tt_fwd_job *jobs, const tt_sample_args *sample, tt_stream_t stream) {
+int tt_mlp_forward_multi_sampled(int n, int count, const tt_fwd_job *jobs, const tt_sample_args *sample, int64_t *k_snapshot,
+                                 tt_stream_t stream) {
     if (!sample) return TT_EINVAL;
-    return forward_multi_impl(n, count, jobs, sample, stream);
+    return forward_multi_impl(n, count, jobs, sample, k_snapshot, stream);
 }
 
 int tt_critic_state_forward(int n, const float *obs, const tt_mlp_weights *w, float *z_state, tt_stream_t stream) {
@@ -1767,7 +1788,20 @@ int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *
 int tt_mlp_backward_rows_pair(int n, float scale_critic, const float *q_out, const tt_mlp_weights *critic,
                               const tt_mlp_saved *saved_critic, const tt_mlp_bwd_ws *ws_critic, const tt_td_input *tdi,
                               const float *mu_out, const tt_mlp_weights *actor, const tt_mlp_saved *saved_actor,
-                              const tt_mlp_bwd_ws *ws_actor, tt_stream_t stream) {
+                              const tt_mlp_bwd_ws *ws_actor, const tt_image_job *image, tt_stream_t stream) {
+    ImageJob ij{};
+    if (image) {
+        const tt_mlp_weights *w = image->actor;
+        const tt_ring_cursor *c = image->cursor;
+        if (!ok_shape(w, false) || !w->split_ws || !c || !c->cursor || !c->k_dev || c->slots <= 0 || (tdi && (c->k_dev == tdi->step_dev ||
+                                                                                                         c->k_dev == tdi->window_dev)))
+            return TT_EINVAL;      // (the cursor's step number must be a word this launch does not advance)
+        ij.W = ttnet::to_weights(w);
+        ij.ws = reinterpret_cast<unsigned char *>(w->split_ws);
+        ij.ws_alt = reinterpret_cast<unsigned char *>(w->split_ws_alt);
+        ij.cur = ttnet::RingCursor{reinterpret_cast<const long long *>(c->k_dev), c->slots, c->cursor};
+        ij.on = 1;
+    }
     if (n <= 0 || !q_out || !mu_out || !ok_shape(critic, true) || !ok_shape(actor, false) || !saved_ok(saved_critic) ||
         !saved_ok(saved_actor) || !ws_ok(ws_critic) || !ws_ok(ws_actor) || !tdi || ws_critic->dx2 == ws_actor->dx2)
         return TT_EINVAL;
@@ -1780,8 +1814,8 @@ int tt_mlp_backward_rows_pair(int n, float scale_critic, const float *q_out, con
     const Saved sa{saved_actor->xh1, saved_actor->h1, saved_actor->xh2, saved_actor->h2, saved_actor->rstd1, saved_actor->rstd2};
     const BwdOut oc{ws_critic->dpre, ws_critic->dz, ws_critic->dx2, ws_critic->dy1, ws_critic->dx1};
     const BwdOut oa{ws_actor->dpre, ws_actor->dz, ws_actor->dx2, ws_actor->dy1, ws_actor->dx1};
-    hipLaunchKernelGGL(k_bwd_rows_pair, dim3(2 * ((n + TR - 1) / TR) + 1), dim3(64 * NW), 0, stream, n, scale_critic, q_out,
-                       to_weights(critic), sc, oc, td, mu_out, to_weights(actor), sa, oa);
+    hipLaunchKernelGGL(k_bwd_rows_pair, dim3(2 * ((n + TR - 1) / TR) + 1 + (ij.on ? IMAGE_WGS : 0)), dim3(64 * NW), 0, stream, n,
+                       scale_critic, q_out, to_weights(critic), sc, oc, td, mu_out, to_weights(actor), sa, oa, ij);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 

@@ -204,10 +204,13 @@ class FusedLearner:
 
     # learn() in the three pieces the two gradient all-reduces cut it into (each piece is pure kernel launches on the
     # current stream, so a data-parallel loop can capture each as a hipGraph and keep only the collectives eager)
-    def phase_a(self, states, actions, rewards, states_, done_u8, fuse_adam, window_dev=None, sample=None):
+    def phase_a(self, states, actions, rewards, states_, done_u8, fuse_adam, window_dev=None, sample=None, image=None):
         """Forwards, TD target, critic backward (+ the critic's Adam/soft update in the same launch when fuse_adam).
         sample: a tt_sample_args (TrajectoryRing.sample_args) whose batch buffers ARE the five tensors given -- the forward
-        launch then makes the replay draw itself (tt_mlp_forward_multi_sampled) instead of reading a batch drawn before."""
+        launch then makes the replay draw itself (tt_mlp_forward_multi_sampled) instead of reading a batch drawn before.
+        image: (packed actor weights struct, tt_ring_cursor whose k_dev is a snapshot word, that word's tensor) -- the critic's
+        backward launch then also packs the vector step's policy image (tt_image_job; needs `sample`: the forward launch leaves
+        the step number in the snapshot word)."""
         ag, B = self.agent, self.B
         self._fresh()
         # DDPG_agent.py:85-93 and :87, :101.  Only the target critic's LAST step needs the target actor's action (it enters
@@ -229,7 +232,8 @@ class FusedLearner:
             jobs[j].dq_da, jobs[j].z_state = None, ptr(zst)
         if sample is not None:
             assert (sample.s_out, sample.a_out, sample.s2_out) == (states.data_ptr(), actions.data_ptr(), states_.data_ptr())
-            L.check(self.lib.tt_mlp_forward_multi_sampled(B, 4, jobs, C.byref(sample), self._stream()))
+            L.check(self.lib.tt_mlp_forward_multi_sampled(B, 4, jobs, C.byref(sample), _p(image[2]) if image is not None else None,
+                                                          self._stream()))
         else:
             L.check(self.lib.tt_mlp_forward_multi(B, 4, jobs, self._stream()))
         # critic step (DDPG_agent.py:95-98); its backward launch first finishes q'(s', mu'(s')) and the TD target for its
@@ -245,7 +249,9 @@ class FusedLearner:
         L.check(self.lib.tt_mlp_backward_rows_pair(B, 2.0 / B, _p(self.q), C.byref(self.w(ag.critic)),
                                                    C.byref(self.critic.saved), C.byref(self.ws), C.byref(td), _p(self.mu),
                                                    C.byref(self.w(ag.actor)), C.byref(self.actor.saved),
-                                                   C.byref(self.ws_actor), self._stream()))
+                                                   C.byref(self.ws_actor),
+                                                   C.byref(L.TTImageJob(C.pointer(image[0]), C.pointer(image[1]))) if image is not None else None,
+                                                   self._stream()))
         self._weights(self.critic, self.hyp_critic, ag.tau, states, actions, self.ws, adam=fuse_adam)
 
     def _weights(self, st, hyp, tau, obs, action, ws, adam, row=None):
@@ -272,13 +278,14 @@ class FusedLearner:
     def phase_c(self):
         self._adam(self.actor, self.hyp_actor, self.agent.tau)
 
-    def learn_batch(self, states, actions, rewards, states_, done_u8, window_dev=None, sample=None):
+    def learn_batch(self, states, actions, rewards, states_, done_u8, window_dev=None, sample=None, image=None):
         """states, states_ [B,23] f32; actions [B,1] f32; rewards [B] f32; done_u8 [B] uint8 -- all contiguous.
         window_dev: device int64 advanced by the critic's backward launch (a pipelined loop's sampling window).
         sample: see phase_a (the five tensors are then the draw's batch buffers, filled by learn()'s first launch)."""
         assert states.shape[0] == self.B and done_u8.dtype == torch.uint8
         dp = self.grad_sync_critic is not None
-        self.phase_a(states, actions, rewards, states_, done_u8, fuse_adam=not dp, window_dev=window_dev, sample=sample)
+        assert image is None or sample is not None
+        self.phase_a(states, actions, rewards, states_, done_u8, fuse_adam=not dp, window_dev=window_dev, sample=sample, image=image)
         if dp:
             self.grad_sync_critic()
         self.phase_b(states, separate_adam=dp)

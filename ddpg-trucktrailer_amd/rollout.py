@@ -120,6 +120,7 @@ class DDPGRollout:
         # in one grid over all CUs
         self.policy_capped_grids = int(os.environ.get("TT_POLICY_CAPPED_GRIDS", policy_capped_grids))
         self.k_pipe_dev = torch.zeros((), dtype=torch.int64, device=self.device)   # steps completed before the running one
+        self._k_snap_dev = torch.zeros((), dtype=torch.int64, device=self.device)  # its value as a learn()'s first launch saw it
         self._pipe_side = None
         if self.pipeline:
             self._pipe_side = torch.cuda.Stream(device=self.device)
@@ -173,7 +174,14 @@ class DDPGRollout:
     def _sample_key(self, u):
         return (self.seed + u * _SEED_STRIDE) & (2 ** 64 - 1)
 
-    def _learn_once(self, u=0, presampled=False):
+    def _image_job(self):
+        """What lets learn()'s second launch carry the pack of the step's policy image (fused_learn.phase_a: image)."""
+        from ddpg_trucktrailer_amd import _lib as L
+        w = fused.packed_weights_of(self.agent.actor, 0, self.policy_workgroups, self.policy_capped_grids, two_images=True)
+        cur = L.TTRingCursor(self._k_snap_dev.data_ptr(), self.ring.slots, 0, self.ring.cursor_dev.data_ptr())
+        return (w, cur, self._k_snap_dev)
+
+    def _learn_once(self, u=0, presampled=False, with_image=False):
         sample = None
         if presampled:         # the step's opening launch already drew this batch into the ring's buffers
             s, a, r, s2, d = self.ring._batch_bufs(self.batch_size)[:5]
@@ -191,13 +199,14 @@ class DDPGRollout:
         if self.learner is not None:
             # (pipelined order) the last update of a vector step moves the sampling window on
             last = self.pipeline and u == self.updates_per_step - 1
-            self.learner.learn_batch(s, a, r, s2, d, window_dev=self.k_pipe_dev if last else None, sample=sample)   # raw uint8 done flags
+            self.learner.learn_batch(s, a, r, s2, d, window_dev=self.k_pipe_dev if last else None, sample=sample,
+                                     image=self._image_job() if with_image else None)   # raw uint8 done flags
         else:
             self.agent.learn_batch(s, a, r, s2, d)
 
-    def _learn_all(self, presampled=False):
+    def _learn_all(self, presampled=False, with_image=False):
         for u in range(self.updates_per_step):
-            self._learn_once(u, presampled and u == 0)
+            self._learn_once(u, presampled and u == 0, with_image and u == 0)
 
     def learn(self):
         if self.ring.k < 2:
@@ -373,11 +382,16 @@ class DDPGRollout:
             with torch.cuda.stream(side):
                 if t >= 2:
                     side.wait_event(stepped[t - 2])
-                self._open_step(True)
                 if edge:
+                    self._open_step(True)
                     opened = torch.cuda.Event()
                     opened.record(side)
-                self._learn_all(presampled=True)
+                    self._learn_all(presampled=True)
+                else:
+                    # no opening launch: learn()'s first launch makes the step's draw, its second one carries the pack of the
+                    # step's image (weights as learn() of step t-1 left them: the actor is next written by the LAST launch of
+                    # this learn()) -- one launch and one dependent boundary less on the learn chain
+                    self._learn_all(presampled=False, with_image=True)
             if edge:
                 cur.wait_event(opened)
             self._act_and_step()

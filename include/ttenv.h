@@ -365,7 +365,10 @@ int tt_mlp_forward_multi(int n, int count, const tt_fwd_job *jobs, tt_stream_t s
  * action sample->a_out -- the workgroups read those rows straight from the ring, and the five batch buffers are filled on
  * the way for the launches that follow (at least one job on s and one on s').  One launch and one dependent launch boundary
  * less per learn() than tt_ring_sample followed by tt_mlp_forward_multi; the same draw, bit for bit. */
-int tt_mlp_forward_multi_sampled(int n, int count, const tt_fwd_job *jobs, const tt_sample_args *sample, tt_stream_t stream);
+/* k_snapshot (may be NULL): *sample->k_dev as this launch saw it, left for a LATER launch that must use the same step number
+ * although the counter moves in between (tt_image_job below). */
+int tt_mlp_forward_multi_sampled(int n, int count, const tt_fwd_job *jobs, const tt_sample_args *sample, int64_t *k_snapshot,
+                                 tt_stream_t stream);
 
 /* The target critic in two pieces, so that its state branch can run NEXT TO the target actor that produces its action:
  * tt_critic_state_forward: z_state [n,300] = bn2(fc2(relu(bn1(fc1(s))))) (networks.py:55-61, before the action enters);
@@ -437,10 +440,19 @@ int tt_mlp_backward_adam(int n, int critic, int mode, float scale, const float *
  *                               Adam + soft update in the same launch when count != 0 (arguments as tt_mlp_backward_adam).
  * Sequence of a learn(): tt_mlp_forward_multi, tt_mlp_backward_rows_pair, tt_mlp_backward_weights(critic), tt_mlp_forward_save
  * (critic on (s, mu(s)) with dq_da), tt_mlp_backward_weights(actor, row_dq_da = dq_da, row_mu = mu, row_scale = -1/B). */
+/* image (may be NULL): the pack of a vector step's policy image (tt_mlp_split_pack with a cursor: image of the step's parity,
+ * ring cursor, image epoch) carried by THIS launch on workgroups of its own -- the actor's weights are not written before
+ * the launch after the next, the pack needs ~5 us of the launch's ~14, and a loop's learn chain is one launch and one dependent
+ * boundary shorter than with an opening pack launch.  image->cursor->k_dev must be a word no launch writes meanwhile
+ * (tt_mlp_forward_multi_sampled: k_snapshot): this launch also advances the step / window counters. */
+typedef struct tt_image_job {
+    const tt_mlp_weights *actor;        /* its split_ws / split_ws_alt are the image buffers (as for tt_mlp_split_pack) */
+    const tt_ring_cursor *cursor;
+} tt_image_job;
 int tt_mlp_backward_rows_pair(int n, float scale_critic, const float *q_out, const tt_mlp_weights *critic,
                               const tt_mlp_saved *saved_critic, const tt_mlp_bwd_ws *ws_critic, const tt_td_input *td,
                               const float *mu_out, const tt_mlp_weights *actor, const tt_mlp_saved *saved_actor,
-                              const tt_mlp_bwd_ws *ws_actor, tt_stream_t stream);
+                              const tt_mlp_bwd_ws *ws_actor, const tt_image_job *image, tt_stream_t stream);
 int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *action, const tt_mlp_saved *saved,
                             const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, const float *row_dq_da, const float *row_mu,
                             float row_scale, int count, float *const *params, float *const *exp_avg, float *const *exp_avg_sq,

@@ -366,3 +366,51 @@ def test_learn_with_the_draw_made_by_its_first_launch(gpu_device, side):
             for x, y in zip(getattr(agents[0], name).state_dict().values(), getattr(agents[1], name).state_dict().values()):
                 assert torch.equal(x, y), (step, name)
         assert torch.equal(learners[0].critic.m, learners[1].critic.m) and torch.equal(learners[0].actor.v, learners[1].actor.v)
+
+
+def test_policy_image_packed_by_learns_second_launch(gpu_device):
+    """tt_image_job: the critic-backward launch of a learn() carries the pack of the vector step's policy image on workgroups of
+    its own.  The image (of the step's parity), the ring cursor and the image epoch it leaves == what tt_mlp_split_pack makes
+    of the actor's weights as they were BEFORE this learn() (the actor is written by learn()'s last launch), bit for bit; the
+    step number comes from the snapshot the forward launch took, not from the counter this launch advances."""
+    import ctypes as C
+    import copy
+    import torch
+    from conftest import GOLDEN
+    from ddpg_trucktrailer_amd import _lib as L, fused
+    from ddpg_trucktrailer_amd.fused_learn import FusedLearner
+    from ddpg_trucktrailer_amd.replay_buffer import TrajectoryRing
+    z = np.load(os.path.join(GOLDEN, "f5_learner.npz"), allow_pickle=False)
+    dev = gpu_device
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    n, slots, B = 512, 16, 256
+    ring = TrajectoryRing(n, slots, 23, dev)
+    ring.obs.copy_(torch.rand(ring.obs.shape, device=dev, generator=g) * 2 - 1)
+    ring.act.copy_(torch.rand(ring.act.shape, device=dev, generator=g) * 2 - 1)
+    ring.rew.copy_(torch.rand(ring.rew.shape, device=dev, generator=g))
+    agent = _agent(dev, z)
+    fl = FusedLearner(agent, B)
+    snap = torch.zeros((), dtype=torch.int64, device=dev)
+    window = torch.zeros((), dtype=torch.int64, device=dev)
+    w = fused.packed_weights_of(agent.actor, 0, 192, 4, two_images=True)
+    images = agent.actor._tt_packed[0][2:4]                      # (even, odd) image buffers of the struct
+    cur = L.TTRingCursor(snap.data_ptr(), slots, 0, ring.cursor_dev.data_ptr())
+    for k in (37, 38):                                           # an odd and an even step
+        ring.k = k; ring.k_dev.fill_(k); window.fill_(k)
+        before = copy.deepcopy(agent.actor)
+        args = ring.sample_args(B, seed=7 + k, k_dev=window, reserve=2, lag=1)
+        s, a, r, s2, d = ring._batch_bufs(B)[:5]
+        for t in images:
+            t.zero_()
+        fl.learn_batch(s, a, r, s2, d, window_dev=window, sample=args, image=(w, cur, snap))
+        torch.cuda.synchronize()
+        assert int(snap.item()) == k and int(window.item()) == k + 1          # the launch read k, then moved the window on
+        ref = torch.empty_like(images[0])
+        L.check(L.load().tt_mlp_split_pack(C.byref(fused.packed_weights_of(before, 0)), 0, C.c_void_p(ref.data_ptr()), None, None,
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        assert torch.equal(images[k & 1], ref), k
+        assert not torch.equal(fused.actor_forward(agent.actor, s).view(-1), fused.actor_forward(before, s).view(-1))   # learn() moved it
+        cw = ring.cursor_dev.cpu().tolist()
+        assert cw[4 + 4 * (k & 1): 8 + 4 * (k & 1)] == [k % slots, (k + 1) % slots, (k - 1) % slots, 1]
+        assert cw[12 + (k & 1)] == k + 1 and cw[14] == 0 and cw[15] == 0
