@@ -374,7 +374,6 @@ def test_policy_image_packed_by_learns_second_launch(gpu_device):
     of the actor's weights as they were BEFORE this learn() (the actor is written by learn()'s last launch), bit for bit; the
     step number comes from the snapshot the forward launch took, not from the counter this launch advances."""
     import ctypes as C
-    import copy
     import torch
     from conftest import GOLDEN
     from ddpg_trucktrailer_amd import _lib as L, fused
@@ -397,7 +396,8 @@ def test_policy_image_packed_by_learns_second_launch(gpu_device):
     cur = L.TTRingCursor(snap.data_ptr(), slots, 0, ring.cursor_dev.data_ptr())
     for k in (37, 38):                                           # an odd and an even step
         ring.k = k; ring.k_dev.fill_(k); window.fill_(k)
-        before = copy.deepcopy(agent.actor)
+        before = _agent(dev, z).actor                          # a second module with the actor's weights of this moment
+        before.load_state_dict(agent.actor.state_dict())
         args = ring.sample_args(B, seed=7 + k, k_dev=window, reserve=2, lag=1)
         s, a, r, s2, d = ring._batch_bufs(B)[:5]
         for t in images:
