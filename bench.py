@@ -439,7 +439,7 @@ def main():
                               "agreed_by_all_ranks": "graph" if loop.dp_single_graph else "segments"}),
                  "env_steps_per_update": n / args.updates_per_step, "setup_vector_steps": loop.vector_steps,
                  "note": ("throughput of the configuration BASELINE.json names; how the same loop trains at this and at other "
-                          "update ratios (--updates-per-step): profiles/r02_training_behaviour.md")}
+                          "update ratios (--updates-per-step): profiles/r03_training_behaviour.md")}
 
     def sync_all():
         torch.cuda.synchronize()
