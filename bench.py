@@ -62,6 +62,10 @@ def parse():
                     "with the two RCCL all-reduces as its nodes; segments: three hipGraph segments with eager all-reduces "
                     "between them; auto: graph where every rank's probe (dp_probe) saw a captured all-reduce replay "
                     "correctly, else segments.  The structure that ran is in config.launch / config.dp_mode")
+    ap.add_argument("--settle-ms", type=float, default=float(os.environ.get("TT_BENCH_SETTLE_MS", "60")),
+                    help="setup ends with this many milliseconds of untimed vector steps (0: none): after the idle of graph capture "
+                         "the GPU needs ~30 ms under load to reach its steady clocks (tools/driver_form.py), more than a short "
+                         "--warmup gives it; the steps are counted in config.setup_vector_steps")
     ap.add_argument("--watchdog-seconds", type=float, default=float(os.environ.get("TT_BENCH_WATCHDOG_S", "300")),
                     help="N > 1: a phase of the run (set-up, warm-up, timed region, ...) that has not completed this many "
                     "seconds after it began ends the rank with exit code 3 and a line that names rank and phase")
@@ -451,6 +455,27 @@ def main():
     if world > 1:
         wd.enter("all-reduce timing")
         ar_us = allreduce_us(dev, world)
+    # Setup ends under load.  The capture above leaves the GPU idle for hundreds of milliseconds and its clocks low; they need
+    # ~30 ms of work to come back (tools/driver_form.py: the first 2 ms region after a 10 ms idle runs 5-9 % slow), which a
+    # warm-up of a few steps does not provide.  Untimed vector steps of the same loop, counted in config.setup_vector_steps;
+    # every rank runs the same number (the data-parallel loop holds collectives).
+    settle_steps = 0
+    if args.settle_ms > 0:
+        wd.enter("settle (steady clocks)")
+        unit = graph_k if ddpg_loop is None else max(1, ddpg_loop.graph_steps)
+        t0 = time.perf_counter()
+        run(unit)
+        sync_all()
+        per_unit = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(per_unit, op=dist.ReduceOp.MIN)
+        reps = min(2000, max(1, int(args.settle_ms * 1e-3 / max(float(per_unit.item()), 1e-6))))
+        run(unit * reps)
+        settle_steps = unit * (reps + 1)
+    extra["setup_vector_steps"] = ddpg_loop.vector_steps if ddpg_loop is not None else settle_steps
+    extra["setup_settle"] = {"ms_asked": args.settle_ms, "vector_steps": settle_steps,
+                             "why": "untimed steps of the same loop right before the warm-up, so that the timed region starts at the "
+                                    "GPU's steady clocks (~30 ms under load after the idle of graph capture); --settle-ms 0 for none"}
     wd.enter("warm-up")
     run(args.warmup)
     sync_all()

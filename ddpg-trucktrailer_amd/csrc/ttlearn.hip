@@ -65,6 +65,10 @@ constexpr int DXS_FLOATS = 16 * DSH;     // ... of the dX2 tile's: 16 x 308 f32,
 __device__ __forceinline__ f32x4 mfma_h(const f16x8 a, const f16x8 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+// (stores of the optimizer state / updated weights / image patches: plain.  Non-temporal ones -- nothing of the same launch reads
+// them again -- made learn() 2 us SLOWER, 66.9 -> 68.9 us: the next launch's row kernels then fetch the weights from memory)
+__device__ __forceinline__ void st_out(float *p, const float v) { *p = v; }
+__device__ __forceinline__ void st_out16(_Float16 *p, const uint4 v) { *reinterpret_cast<uint4 *>(p) = v; }
 // the two pieces of one fc2 weight into an image: element (n = output neuron, k = input)
 __device__ __forceinline__ void img_store(_Float16 *__restrict__ img, const int n, const int k, const float w, const bool with_t) {
     const float s = w * SWL;
@@ -1095,15 +1099,15 @@ __device__ __forceinline__ float2 adam_finish(const AdamFused &A, const int t, c
     const float g = fmaf(A.weight_decay, e.p, grad);
     const float m = fmaf(A.beta1, e.m, (1.f - A.beta1) * g);
     const float v = fmaf(A.beta2, e.v, (1.f - A.beta2) * g * g);
-    A.m[t][i] = m;
-    A.v[t][i] = v;
+    st_out(&A.m[t][i], m);
+    st_out(&A.v[t][i], v);
     const float denom = sqrtf(v) / sqrt_bc2 + A.eps;
     const float p = e.p - (A.lr / bc1) * (m / denom);
-    A.p[t][i] = p;
+    st_out(&A.p[t][i], p);
     float tg = e.tg;
     if (A.tgt[t]) {
         tg = fmaf(A.tau, p - e.tg, e.tg);
-        A.tgt[t][i] = tg;
+        st_out(&A.tgt[t][i], tg);
     }
     return make_float2(p, tg);
 }
@@ -1119,12 +1123,12 @@ __device__ __forceinline__ void adam_finish(const AdamFused &A, const AdamPtrs &
     const float g = fmaf(A.weight_decay, e.p, grad);
     const float m = fmaf(A.beta1, e.m, (1.f - A.beta1) * g);
     const float v = fmaf(A.beta2, e.v, (1.f - A.beta2) * g * g);
-    q.m[i] = m;
-    q.v[i] = v;
+    st_out(&q.m[i], m);
+    st_out(&q.v[i], v);
     const float denom = sqrtf(v) / sqrt_bc2 + A.eps;
     const float p = e.p - (A.lr / bc1) * (m / denom);
-    q.p[i] = p;
-    if (q.tgt) q.tgt[i] = fmaf(A.tau, p - e.tg, e.tg);
+    st_out(&q.p[i], p);
+    if (q.tgt) st_out(&q.tgt[i], fmaf(A.tau, p - e.tg, e.tg));
 }
 
 // Optional per-row factor of k_bwd_weights' inputs: row b of dpre / dz / dx2 / dy1 / dx1 (a unit backward, mode 3) counts
@@ -1297,7 +1301,7 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
                 const int jr = jt * 16 + l4 * 4 + r;
                 if (jr < H2) {
                     const float g = ((p0[r] + p1[r]) + p2[r]) + p3[r];
-                    G.w2[(size_t)jr * H1 + col] = g;
+                    st_out(&G.w2[(size_t)jr * H1 + col], g);
                     if (A.on) {
                         const float2 pt = adam_finish(A, 4, (size_t)jr * H1 + col, g, el[r], bc1, sqrt_bc2);
                         pnew[r] = pt.x; tnew[r] = pt.y;
@@ -1333,11 +1337,11 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
                     if (A.img_p) {
                         const size_t o = 2 * IMG_FWD + (arr == 3 ? IMG_T : 0) +
                                          ((size_t)((grp * 4 + (w >> 5)) * BW_STEPS + (jt >> 1)) * 64 + (jt & 1) * 32) * 8 + (w & 31) * 8;
-                        *reinterpret_cast<uint4 *>(A.img_p + o) = v;
+                        st_out16(A.img_p + o, v);
                     }
                 } else if (w < fcount) {
                     _Float16 *img = arr < 2 ? A.img_p : (A.tgt[4] ? A.img_t : nullptr);
-                    if (img) *reinterpret_cast<uint4 *>(img + ((arr & 1) ? IMG_FWD : 0) + fbase + w * 8) = v;
+                    if (img) st_out16(img + ((arr & 1) ? IMG_FWD : 0) + fbase + w * 8, v);
                 }
             }
         }
@@ -1407,7 +1411,7 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
             for (int r = 0; r < 4; ++r) {
                 const float g = ((part[0][wave][lane * 4 + r] + part[1][wave][lane * 4 + r]) + part[2][wave][lane * 4 + r]) +
                                 part[3][wave][lane * 4 + r];
-                G.w1[(size_t)(jt * 16 + l4 * 4 + r) * IN + col] = g;
+                st_out(&G.w1[(size_t)(jt * 16 + l4 * 4 + r) * IN + col], g);
                 if (A.on) adam_finish(A, 0, (size_t)(jt * 16 + l4 * 4 + r) * IN + col, g, el[r], bc1, sqrt_bc2);
             }
         }
@@ -1502,7 +1506,7 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
         lds_barrier();
         if (wave == 0 && valid) {
             const float total = ((part[0][0][lane] + part[1][0][lane]) + part[2][0][lane]) + part[3][0][lane];
-            outp[c] = total;
+            st_out(&outp[c], total);
             if (A.on) adam_finish(A, ad, (size_t)c, total, e0, bc1, sqrt_bc2);
         }
         STAMPB(6, NU2 + NU1);

@@ -83,6 +83,8 @@ def main():
         torch.cuda.synchronize()
         report(read(lib), f"learn() alone, third of three back-to-back hipGraph replays (repeat {rep})")
         phases(lib)
+    if os.environ.get("TT_LB_SHORT") == "1":
+        return
     from ddpg_trucktrailer_amd.rollout import DDPGRollout
     from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
@@ -94,6 +96,21 @@ def main():
         loop.run(20)
         torch.cuda.synchronize()
         report(read(lib), f"learn() of the LAST step of a 20-step graph of the N = {n} loop (policy grids beside it) (repeat {rep})")
+        phases(lib)
+    # several updates per vector step: the LAST update of the last step runs alone on the chip (the policy and env launches of
+    # the step are long over), after 63 others back to back
+    del loop
+    U = int(os.environ.get("TT_UPDATES", "64"))
+    env = TruckTrailerVecEnv(n); env.reset(seed=27)
+    loop = DDPGRollout(env, batch_size=256, replay_slots=64, seed=27, graph_steps=4, updates_per_step=U)
+    loop.run(4 + 4 + 4 + 1)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); loop.run(8); e1.record()
+        torch.cuda.synchronize()
+        print(f"{U} updates per step, N = {n}: {e0.elapsed_time(e1) * 1000 / 8 / U:.2f} us per update")
+        report(read(lib), f"the LAST of {U} updates of the last step of a 4-step graph (repeat {rep})")
         phases(lib)
 
 

@@ -20,7 +20,9 @@ for b in range(steps // block):
     flat = torch.cat([p.detach().reshape(-1) for net in loop.agent._nets() for p in net.parameters()])
     ok = bool(torch.isfinite(flat).all()) and bool(torch.isfinite(loop.ring.obs).all()) and bool(torch.isfinite(env.state).all())
     print(f"block {b}: {rates[-1]:.3e} env-steps/s  finite={ok}  k={loop.ring.k} k_dev={int(loop.ring.k_dev.item())} "
-          f"k_pipe={int(loop.k_pipe_dev.item())} learn steps={int(loop.learner.step_dev.item())} max|w|={flat.abs().max().item():.3f}", flush=True)
+          f"k_pipe={int(loop.k_pipe_dev.item())} learn steps={int(loop.learner.step_dev.item())} max|w|={flat.abs().max().item():.3f} "
+          f"image hand-over: {loop.policy_edge()}, gave up {loop.ring.policy_gave_up()}", flush=True)
+    assert loop.ring.policy_gave_up() == 0
     assert ok and loop.ring.k == int(loop.ring.k_dev.item()) == int(loop.k_pipe_dev.item())
 assert loop.learner.images_current()
 print("soak ok: first/last block rate ratio %.3f" % (rates[-1] / rates[0]))
