@@ -62,10 +62,11 @@ def parse():
                     "with the two RCCL all-reduces as its nodes; segments: three hipGraph segments with eager all-reduces "
                     "between them; auto: graph where every rank's probe (dp_probe) saw a captured all-reduce replay "
                     "correctly, else segments.  The structure that ran is in config.launch / config.dp_mode")
-    ap.add_argument("--settle-ms", type=float, default=float(os.environ.get("TT_BENCH_SETTLE_MS", "60")),
-                    help="setup ends with this many milliseconds of untimed vector steps (0: none): after the idle of graph capture "
-                         "the GPU needs ~30 ms under load to reach its steady clocks (tools/driver_form.py), more than a short "
-                         "--warmup gives it; the steps are counted in config.setup_vector_steps")
+    ap.add_argument("--settle-ms", type=float, default=None,
+                    help="setup ends with this many milliseconds of untimed vector steps (default: 100 for the ddpg workload, env "
+                         "TT_BENCH_SETTLE_MS; 0: none): after the idle of graph capture the GPU needs ~30 ms under load to reach its "
+                         "steady clocks (tools/driver_form.py), more than a short --warmup gives it; the steps are counted in "
+                         "config.setup_vector_steps")
     ap.add_argument("--watchdog-seconds", type=float, default=float(os.environ.get("TT_BENCH_WATCHDOG_S", "300")),
                     help="N > 1: a phase of the run (set-up, warm-up, timed region, ...) that has not completed this many "
                     "seconds after it began ends the rank with exit code 3 and a line that names rank and phase")
@@ -460,6 +461,8 @@ def main():
     # warm-up of a few steps does not provide.  Untimed vector steps of the same loop, counted in config.setup_vector_steps;
     # every rank runs the same number (the data-parallel loop holds collectives).
     settle_steps = 0
+    if args.settle_ms is None:     # (the env workload's 0.2 ms regions gain nothing: 9.2 -> 8.9 us per step on the GPU's clock, but
+        args.settle_ms = float(os.environ.get("TT_BENCH_SETTLE_MS", "100")) if ddpg_loop is not None else 0.0   # +15 us of host time)
     if args.settle_ms > 0:
         wd.enter("settle (steady clocks)")
         unit = graph_k if ddpg_loop is None else max(1, ddpg_loop.graph_steps)
@@ -470,7 +473,9 @@ def main():
         if world > 1:
             dist.all_reduce(per_unit, op=dist.ReduceOp.MIN)
         reps = min(2000, max(1, int(args.settle_ms * 1e-3 / max(float(per_unit.item()), 1e-6))))
-        run(unit * reps)
+        for _ in range(reps):       # a synchronize per unit: hundreds of queued replays leave the runtime resources to reclaim,
+            run(unit)               # and it does that in the next synchronize -- the timed region's (0.3 ms, tools/r03_j.sh)
+            sync_all()
         settle_steps = unit * (reps + 1)
     extra["setup_vector_steps"] = ddpg_loop.vector_steps if ddpg_loop is not None else settle_steps
     extra["setup_settle"] = {"ms_asked": args.settle_ms, "vector_steps": settle_steps,

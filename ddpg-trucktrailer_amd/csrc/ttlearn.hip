@@ -606,6 +606,14 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
     const int job = blockIdx.x / J.blocks_per_job, row0 = (blockIdx.x - job * J.blocks_per_job) * TR;
     const FwdJob &q = J.j[job];
     KBEGIN(0);
+#ifdef TT_STAMPS   // the last end of the PREVIOUS learn()'s last launch, before this learn() overwrites anything: [5][0][0]
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        unsigned long long m = 0;
+        for (int i = threadIdx.x; i < 512; i += 64) m = max(m, g_kblk[4][i][1]);
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned long long)__shfl_xor((long long)m, o));
+        if (threadIdx.x == 0) g_kblk[5][0][0] = m;
+    }
+#endif
     static_assert(TR / NW == 2, "two rows per wave");
     const float *orow = nullptr;
     bool have_act = false;
@@ -625,6 +633,8 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
         }
         if (job == J.write_s || job == J.write_s2) {
             // the batch rows of this workgroup for the later launches: thread i < 16 x 23 copies one feature
+            // (loads here and the stores after the forward -- so that its own loads do not queue behind this copy -- changed
+            // nothing: 18.2 us for the slowest workgroup either way)
             const int lr = tid / ttnet::IN, c = tid - lr * ttnet::IN, b = row0 + lr;
             if (lr < TR && b < J.n) {
                 const ttnet::RingPick p = ttnet::ring_sample_index(J.R, b);

@@ -330,7 +330,7 @@ static int make_sample(int batch, int n_envs, int slots, const int64_t *k_dev, c
                        float *s_out, float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out,
                        RingSample &R) {
     const tt_sample_args a{batch, n_envs, slots, reserve, k_dev, obs, act, rew, done, seed, side, s_out, a_out, r_out, s2_out,
-                           d_out, idx_out, lag, 0};
+                           d_out, idx_out, lag, 1, 0};
     return make_ring_sample(&a, R);
 }
 
@@ -368,6 +368,8 @@ int tt_mlp_split_pack_and_sample(const tt_mlp_weights *w, int critic, void *ws, 
     const int rc = make_sample(a->batch, a->n_envs, a->slots, a->k_dev, a->obs, a->act, a->rew, a->done, a->seed, a->reserve,
                                a->lag, a->side, a->s_out, a->a_out, a->r_out, a->s2_out, a->d_out, a->idx_out, R);
     if (rc != TT_OK) return rc;
+    if (a->draws < 0 || (long long)(a->draws > 1 ? a->draws : 1) * a->batch > (1 << 24)) return TT_EINVAL;
+    if (a->draws > 1) { R.draws = a->draws; R.seed_stride = a->seed_stride; }
     return split_pack_and_sample(w, critic != 0, ws, R, to_cursor(cursor), stream);
 }
 

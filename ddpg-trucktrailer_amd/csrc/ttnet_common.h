@@ -122,6 +122,8 @@ struct RingSample {
     float *s_out, *a_out, *r_out, *s2_out;
     uint8_t *d_out;
     int *idx_out;
+    int draws;                         // draws of `batch` rows each in one launch (k_pack_and_sample only; else 1)
+    unsigned long long seed_stride;    // draw u uses seed + u * seed_stride
 };
 
 // where batch row b of a draw comes from: a side tuple j (side = true) or ring transition (slot t, env e), t1 = the slot of s'
@@ -129,7 +131,7 @@ struct RingPick {
     bool side;
     int j, t, t1, e;
 };
-__device__ inline RingPick ring_sample_index(const RingSample &R, const int b) {
+__device__ inline RingPick ring_sample_index(const RingSample &R, const int b, const unsigned long long seed) {
     const int n_envs = R.n_envs, slots = R.slots;
     // vector steps completed; transitions k-avail .. k-1 are intact.  lag: that many of the newest steps may still be under
     // way on another stream when this draw runs (a loop whose learn() chain runs ahead of its env steps)
@@ -137,7 +139,7 @@ __device__ inline RingPick ring_sample_index(const RingSample &R, const int b) {
     const long long cap = slots - 1 - R.reserve;      // reserve: slots a concurrent env step is overwriting (pipelined loop)
     const long long avail = k < cap ? k : cap;
     uint32_t r[4];
-    philox4x32((uint32_t)b, (uint32_t)k, (uint32_t)(k >> 32), 0x5A3Du, (uint32_t)R.seed, (uint32_t)(R.seed >> 32), r);
+    philox4x32((uint32_t)b, (uint32_t)k, (uint32_t)(k >> 32), 0x5A3Du, (uint32_t)seed, (uint32_t)(seed >> 32), r);
     RingPick p{false, 0, 0, 0, 0};
     if (R.side.count > 0) {
         const unsigned long long in_ring = (unsigned long long)avail * (unsigned long long)n_envs;
@@ -154,6 +156,7 @@ __device__ inline RingPick ring_sample_index(const RingSample &R, const int b) {
     p.e = (int)(((unsigned long long)r[1] * (unsigned long long)n_envs) >> 32);
     return p;
 }
+__device__ inline RingPick ring_sample_index(const RingSample &R, const int b) { return ring_sample_index(R, b, R.seed); }
 // the picked transition's pieces
 __device__ __forceinline__ const float *ring_pick_s(const RingSample &R, const RingPick &p) {
     return p.side ? R.side.obs + (size_t)p.j * IN : R.obs + ((size_t)p.t * R.n_envs + p.e) * IN;
@@ -171,8 +174,10 @@ __device__ __forceinline__ uint8_t ring_pick_d(const RingSample &R, const RingPi
     return p.side ? R.side.done[p.j] : R.done[(size_t)p.t * R.n_envs + p.e];
 }
 
+// b: row of the output buffers = draw (b / batch), row (b % batch) of that draw
 __device__ inline void ring_sample_row(const RingSample &R, const int b, const int lane) {
-    const RingPick p = ring_sample_index(R, b);
+    const int u = R.draws > 1 ? b / R.batch : 0;
+    const RingPick p = ring_sample_index(R, b - u * R.batch, R.seed + (unsigned long long)u * R.seed_stride);
     const float *src = ring_pick_s(R, p), *src2 = ring_pick_s2(R, p);
     if (lane < IN) R.s_out[(size_t)b * IN + lane] = src[lane];
     else if (lane >= 32 && lane < 32 + IN) R.s2_out[(size_t)b * IN + lane - 32] = src2[lane - 32];
@@ -196,7 +201,7 @@ inline int make_ring_sample(const tt_sample_args *a, RingSample &R) {
         sb = SideBuf{sd->obs, sd->act, sd->rew, sd->obs2, sd->done, sd->count};
     }
     R = RingSample{a->batch, a->n_envs, a->slots, a->reserve, a->lag, reinterpret_cast<const long long *>(a->k_dev), a->obs, a->act,
-                   a->rew, a->done, a->seed, sb, a->s_out, a->a_out, a->r_out, a->s2_out, a->d_out, a->idx_out};
+                   a->rew, a->done, a->seed, sb, a->s_out, a->a_out, a->r_out, a->s2_out, a->d_out, a->idx_out, 1, 0ull};
     return TT_OK;
 }
 

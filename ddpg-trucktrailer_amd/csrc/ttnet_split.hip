@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void k_split_pack(const Weights W, const bool 
 
 // What opens a pipelined vector step, in ONE launch (two small kernels would each cost their ~4 us of launch and a
 // dependency gap on the loop's critical path): the policy's image from the actor's current weights, and the first batch of
-// this step's learn() from the replay ring (four sampled transitions per 256-thread workgroup).
+// this step's learn() -- or all of its batches, one per update (RingSample.draws) -- from the replay ring (four sampled
+// transitions per 256-thread workgroup).
 __global__ __launch_bounds__(256) void k_pack_and_sample(const Weights W, const bool critic, unsigned char *__restrict__ ws,
                                                          unsigned char *__restrict__ ws_alt, const RingSample R,
                                                          const RingCursor cur) {
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void k_pack_and_sample(const Weights W, const 
         return;
     }
     const int b = ((int)blockIdx.x - PACK_BLOCKS) * 4 + (threadIdx.x >> 6);
-    if (b < R.batch) ring_sample_row(R, b, threadIdx.x & 63);
+    if (b < R.batch * R.draws) ring_sample_row(R, b, threadIdx.x & 63);
 }
 
 // LDS reads through laundered address-space-3 bases.  The ring + vectors span 152 KB and a ds_read's immediate offset reaches
@@ -487,7 +488,7 @@ int split_pack(const tt_mlp_weights *w, bool critic, void *ws, long long *bump, 
 int split_pack_and_sample(const tt_mlp_weights *w, bool critic, void *ws, const RingSample &R, const RingCursor &cur,
                           hipStream_t stream) {
     unsigned char *alt = ws == w->split_ws ? reinterpret_cast<unsigned char *>(w->split_ws_alt) : nullptr;
-    hipLaunchKernelGGL(k_pack_and_sample, dim3(PACK_BLOCKS + (R.batch + 3) / 4), dim3(256), 0, stream, to_weights(w), critic,
+    hipLaunchKernelGGL(k_pack_and_sample, dim3(PACK_BLOCKS + (R.batch * R.draws + 3) / 4), dim3(256), 0, stream, to_weights(w), critic,
                        reinterpret_cast<unsigned char *>(ws), alt, R, cur);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }

@@ -193,17 +193,20 @@ class TrajectoryRing:
         self._bufs = cache[batch_size]          # (the set of the latest draw)
         return self._bufs
 
-    def sample_args(self, batch_size, seed=0, k_dev=None, reserve=0, lag=0):
-        """tt_sample_args for one draw into the ring's batch buffers (include/ttenv.h); keeps what it points at alive."""
+    def sample_args(self, batch_size, seed=0, k_dev=None, reserve=0, lag=0, draws=1, seed_stride=0):
+        """tt_sample_args for one draw into the ring's batch buffers (include/ttenv.h); keeps what it points at alive.
+        draws > 1 (tt_mlp_split_pack_and_sample only): that many draws of batch_size rows, draw u with seed + u * seed_stride
+        into rows [u * batch_size, (u + 1) * batch_size) of the buffers _batch_bufs(draws * batch_size)."""
         from ddpg_trucktrailer_amd import _lib as L
-        s, a, r, s2, dn, idx = self._batch_bufs(batch_size)
+        s, a, r, s2, dn, idx = self._batch_bufs(batch_size * max(1, int(draws)))
         p = lambda t: t.data_ptr()
         side = self._side_struct()
         self._side_keep = side
         import ctypes as C
         return L.TTSampleArgs(batch_size, self.n, self.slots, int(reserve), p(self.k_dev if k_dev is None else k_dev),
                               p(self.obs), p(self.act), p(self.rew), p(self.done), int(seed) & (2 ** 64 - 1),
-                              C.pointer(side) if side is not None else None, p(s), p(a), p(r), p(s2), p(dn), p(idx), int(lag), 0)
+                              C.pointer(side) if side is not None else None, p(s), p(a), p(r), p(s2), p(dn), p(idx), int(lag),
+                              max(1, int(draws)), int(seed_stride) & (2 ** 64 - 1))
 
     def sample_fused(self, batch_size, seed=0, return_index=False, done_as_bool=True, k_dev=None, reserve=0, lag=0):
         """sample() as ONE HIP launch (tt_ring_sample): Philox indices keyed by (seed, k_dev) + gather.

@@ -184,7 +184,8 @@ class DDPGRollout:
     def _learn_once(self, u=0, presampled=False, with_image=False):
         sample = None
         if presampled:         # the step's opening launch already drew this batch into the ring's buffers
-            s, a, r, s2, d = self.ring._batch_bufs(self.batch_size)[:5]
+            B, draws = self.batch_size, self._draws_per_opening()
+            s, a, r, s2, d = (x[u * B:(u + 1) * B] for x in self.ring._batch_bufs(B * draws)[:5])
         elif self.learner is not None and self.device.type == "cuda":
             # the fused learner's first launch makes the draw itself (tt_mlp_forward_multi_sampled): the same draw as
             # _sample(u), one launch less per update
@@ -204,9 +205,19 @@ class DDPGRollout:
         else:
             self.agent.learn_batch(s, a, r, s2, d)
 
+    def _draws_per_opening(self):
+        """Batches the opening launch of a pipelined step draws: all of the step's updates' (tt_sample_args.draws) -- each the
+        draw its own update would make (same window, seed of update u), but made once per step, so that no update waits for
+        the ring's rows on the learn chain (2.9 us per update).  Data-parallel ranks and the
+        torch learner keep one draw per opening launch."""
+        multi = (self.updates_per_step > 1 and self.pipeline and self.learner is not None and not self.dp
+                 and self.device.type == "cuda" and os.environ.get("TT_MULTI_DRAW", "1") == "1")
+        return self.updates_per_step if multi else 1
+
     def _learn_all(self, presampled=False, with_image=False):
+        draws = self._draws_per_opening() if presampled else 1
         for u in range(self.updates_per_step):
-            self._learn_once(u, presampled and u == 0, with_image and u == 0)
+            self._learn_once(u, presampled and u < draws, with_image and u == 0)
 
     def learn(self):
         if self.ring.k < 2:
@@ -246,8 +257,8 @@ class DDPGRollout:
         the step -- in the pipelined order also the first batch of the step's learn()."""
         if self.pipeline and learn:
             fused.pack_and_sample(self.agent.actor, 0, self.ring.sample_args(
-                self.batch_size, seed=self._sample_key(0), k_dev=self.k_pipe_dev, reserve=_PIPE_RESERVE, lag=_PIPE_LAG),
-                cursor=self.ring.cursor(self.k_pipe_dev))
+                self.batch_size, seed=self._sample_key(0), k_dev=self.k_pipe_dev, reserve=_PIPE_RESERVE, lag=_PIPE_LAG,
+                draws=self._draws_per_opening(), seed_stride=_SEED_STRIDE), cursor=self.ring.cursor(self.k_pipe_dev))
         elif self.pipeline:
             fused.pack(self.agent.actor, 0, cursor=self.ring.cursor(self.k_pipe_dev))
         else:
@@ -413,6 +424,7 @@ class DDPGRollout:
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         ring._batch_bufs(self.batch_size)       # (allocated before the capture; kept per batch size for the ring's lifetime)
+        ring._batch_bufs(self.batch_size * self._draws_per_opening())
         lagged = self.pipeline and not (self.dp and not self.dp_single_graph)
         many = (lambda k: (lambda: self._capture_lagged(k))) if lagged else (lambda k: (lambda: [self._capture_body() for _ in range(k)]))
         self.graph1 = self._capture(many(1), side)

@@ -324,7 +324,13 @@ typedef struct tt_sample_args {
     float *s_out, *a_out, *r_out, *s2_out;
     uint8_t *d_out;
     int32_t *idx_out;
-    int32_t lag, reserved_;  /* lag: the newest `lag` steps counted by *k_dev may still be under way (tt_ring_sample) */
+    int32_t lag;             /* the newest `lag` steps counted by *k_dev may still be under way (tt_ring_sample) */
+    int32_t draws;           /* tt_mlp_split_pack_and_sample: 0 or 1 = one draw; d > 1 = d draws of `batch` rows each from the SAME
+                              * window in the one launch -- draw u uses seed + u * seed_stride and fills rows [u * batch, (u + 1) *
+                              * batch) of the output buffers (sized for d * batch rows): the batches of all the learn() calls of one
+                              * vector step (each of them exactly what its own tt_ring_sample with that seed would draw), so that
+                              * none of them has the ring's latency on its chain.  Other entry points take one draw and ignore it */
+    uint64_t seed_stride;
 } tt_sample_args;
 int tt_mlp_split_pack_and_sample(const tt_mlp_weights *w, int critic, void *ws, const tt_sample_args *sample,
                                  const tt_ring_cursor *cursor, tt_stream_t stream);

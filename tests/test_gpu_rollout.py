@@ -157,6 +157,33 @@ def test_fused_ring_sampling(gpu_device):
     assert not torch.equal(again, ring.sample_fused(B, seed=5, return_index=True)[5])
 
 
+def test_several_draws_in_the_opening_launch(gpu_device):
+    """tt_mlp_split_pack_and_sample with tt_sample_args.draws = 3: rows [u B, (u + 1) B) of the buffers are exactly what
+    tt_ring_sample draws with seed + u * seed_stride (same window, same side tuples), including the index pairs."""
+    import torch
+    from ddpg_trucktrailer_amd import fused
+    from ddpg_trucktrailer_amd.agent import Agent
+    from ddpg_trucktrailer_amd.replay_buffer import TrajectoryRing
+    n, slots, B, U, stride = 500, 7, 96, 3, 0x9E3779B97F4A7C15
+    g = torch.Generator(device="cpu").manual_seed(3)
+    ring = TrajectoryRing(n, slots, 23, gpu_device)
+    ring.obs.copy_(torch.rand(ring.obs.shape, generator=g)); ring.act.copy_(torch.rand(ring.act.shape, generator=g))
+    ring.rew.copy_(torch.rand(ring.rew.shape, generator=g)); ring.done.copy_((torch.rand(ring.done.shape, generator=g) < 0.2).to(torch.uint8))
+    ring.load_side(torch.rand((40, 23), generator=g), torch.rand(40, generator=g), torch.rand(40, generator=g),
+                   torch.rand((40, 23), generator=g), torch.rand(40, generator=g) < 0.5)
+    for _ in range(9):
+        ring.advance()
+    actor = Agent(1e-4, 1e-3, (23,), 1e-3, 1, batch_size=B, device=gpu_device, replay=False).actor
+    fused.pack_and_sample(actor, 0, ring.sample_args(B, seed=11, reserve=2, lag=1, draws=U, seed_stride=stride))
+    big = [x.clone() for x in ring._batch_bufs(U * B)]
+    for u in range(U):
+        one = ring.sample_fused(B, seed=(11 + u * stride) & (2 ** 64 - 1), return_index=True, done_as_bool=False, reserve=2, lag=1)
+        for x, y in zip(big, one):
+            assert torch.equal(x[u * B:(u + 1) * B].reshape(B, -1), y.reshape(B, -1))
+    assert (big[5][:, 0] == -1).any() and (big[5][:, 0] >= 0).any()          # side tuples and ring rows both took part
+    assert not torch.equal(big[0][:B], big[0][B:2 * B])
+
+
 def test_whole_step_graphs_match_eager_steps(gpu_device):
     """DDPGRollout.run(k) replays hipGraphs of whole vector steps (policy + env step + learn); step() launches the same
     vector step eagerly.  Everything that varies per step lives on the device (ring counter, Philox counters), so the two
@@ -252,6 +279,45 @@ def test_updates_per_step(gpu_device):
     assert torch.equal(_loop_flat(a), _loop_flat(b))
     s0 = a._sample(0)[0].clone(); s1 = a._sample(1)[0].clone()
     assert not torch.equal(s0, s1), "the updates of one vector step must draw different batches"
+    for lp in loops:
+        lp.env.close()
+
+
+@pytest.mark.parametrize("side", [False, True])
+def test_all_batches_of_a_step_from_its_opening_launch(gpu_device, monkeypatch, side):
+    """Several updates per step: the opening launch of a step makes ALL of the step's draws (tt_sample_args.draws), each into its
+    rows of one buffer -- bit for bit the batches the updates' own draws (learn()'s first launch, TT_MULTI_DRAW=0) would be, so
+    the loop's state after 14 steps is the same either way, in graphs and eagerly; with expert tuples in the draw as well."""
+    import torch
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    loops = []
+    for multi, graph_steps in (("1", 4), ("0", 4), ("1", 0)):
+        monkeypatch.setenv("TT_MULTI_DRAW", multi)
+        env = TruckTrailerVecEnv(4096)
+        env.reset(seed=5)
+        lp = DDPGRollout(env, batch_size=256, replay_slots=8, seed=5, graph_steps=graph_steps, updates_per_step=4)
+        assert lp._draws_per_opening() == (4 if multi == "1" else 1)
+        if side:
+            g = torch.Generator().manual_seed(1)
+            k = 3000
+            lp.ring.load_side(torch.rand((k, 23), generator=g), torch.rand(k, generator=g) * 2 - 1, -torch.rand(k, generator=g),
+                              torch.rand((k, 23), generator=g), torch.rand(k, generator=g) < 0.1)
+        if graph_steps:
+            lp.run(14)
+        else:
+            for _ in range(14):
+                lp.step()
+        loops.append(lp)
+    torch.cuda.synchronize()
+    a, b, c = loops
+    assert int(a.learner.step_dev.item()) == int(b.learner.step_dev.item()) == int(c.learner.step_dev.item()) == 4 * 12
+    assert torch.equal(_loop_flat(a), _loop_flat(b))
+    assert torch.equal(_loop_flat(a), _loop_flat(c))
+    # the rows of the big buffer are the four batches: draw u of the last step == the draw an update makes on its own
+    B = 256
+    big = a.ring._batch_bufs(4 * B)[0].clone()
+    assert not torch.equal(big[:B], big[B:2 * B])
     for lp in loops:
         lp.env.close()
 

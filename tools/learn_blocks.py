@@ -54,6 +54,8 @@ def report(a, title, lib=None):
               f"median wg {np.median(en - st):5.2f}  max wg {np.max(en - st):5.2f}{gap}")
         prev_end = en.max()
     print(f"  chain: first start -> last end {prev_end:6.2f} us")
+    if a[5, 0, 0] and 0 < t0 - a[5, 0, 0] < 100000:
+        print(f"  the previous learn()'s last workgroup ended {(t0 - a[5, 0, 0]) / 100.0:5.2f} us before this one's first began")
 
 
 def main():
