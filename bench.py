@@ -484,6 +484,28 @@ def main():
     wd.enter("warm-up")
     run(args.warmup)
     sync_all()
+    # The policy launch of a captured step waits for its image in device memory (include/ttenv.h: image hand-over), bounded:
+    # a launch that left by its time limit -- it never has on this stack (tests at this graph length, 200 k-step soaks), but which
+    # hardware queue the runtime gives a graph's chain is not a promise -- means the chains did not run beside each other.
+    # Seen BEFORE the timed region it costs the run nothing but the hand-over: the graphs are captured again with a graph edge
+    # (0.096 instead of 0.092 ms per step), and the line says so.  Inside the timed region it fails the run (below).
+    handover_fallback = False
+    if ddpg_loop is not None and ddpg_loop.ring_mode and ddpg_loop.graph_steps and ddpg_loop.policy_edge() == "flag":
+        if os.environ.get("TT_BENCH_TEST_GAVE_UP") == "1":      # (tests/test_gpu_bench_line.py: the fallback below must work)
+            ddpg_loop.ring.cursor_dev[15] = 1
+        if ddpg_loop.ring.policy_gave_up():
+            print("bench.py: a policy launch gave up waiting for its image during setup; capturing the steps again with a graph "
+                  "edge into the policy launch (TT_POLICY_EDGE=graph)", file=sys.stderr, flush=True)
+            wd.enter("prepare again (graph edge)")
+            os.environ["TT_POLICY_EDGE"] = "graph"
+            handover_fallback = True
+            ddpg_loop.ring.cursor_dev[15] = 0
+            ddpg_loop.invalidate_graphs()
+            ddpg_loop.prepare()
+            ddpg_loop.first_launches()
+            run(max(args.warmup, ddpg_loop.graph_steps))
+            sync_all()
+            extra["setup_vector_steps"] = ddpg_loop.vector_steps
     wd.enter("timed region")
     captured = graph_k > 1 or (ddpg_loop is not None and ddpg_loop.graph_steps > 0)
     if not captured:
@@ -578,6 +600,8 @@ def main():
         gave_up = ddpg_loop.ring.policy_gave_up()      # (device-memory hand-over of the policy image: include/ttenv.h)
         assert gave_up == 0, f"a policy launch gave up waiting for the image of step {gave_up - 1}"
         out["config"]["policy_image_handover"] = ("graph edge" if ddpg_loop.policy_edge() == "graph" else "device memory (epoch word)")
+        if handover_fallback:
+            out["config"]["policy_image_handover"] += " (fallback: a policy launch gave up waiting during setup)"
     if ar_us is not None:
         out["allreduce_us"] = ar_us
     if rank == 0:

@@ -167,6 +167,11 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # torch first: it brings its own copy of the HIP runtime (torch/lib/libamdhip64.so, loaded by path), and libttenv.so then
+        # binds to that copy by its soname.  The other way round the process holds TWO runtimes -- /opt/rocm's for this library,
+        # torch's for the tensors it is handed -- and tt_env_create finds no device in its own (seen on the GPU box with
+        # `g.build(); g.smoke()`, where build() loaded the library before anything had imported torch)
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)

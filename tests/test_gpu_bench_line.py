@@ -42,3 +42,18 @@ def test_driver_form_line_holds_the_contract(gpu_device):
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["unit"] == "env-steps/s" and cpu["value"] > 0 and cpu["sample"]
     mf = d["roofline_mfma"]
     assert mf["bound"] == "mfma" and 0.0 < mf["frac"] < 1.0
+
+
+def test_fallback_to_a_graph_edge_when_a_policy_launch_gave_up_in_setup(gpu_device):
+    """The policy launch of a captured step waits for its image in device memory, with a time limit.  bench.py looks at the
+    give-up word after its warm-up; if it is set, the steps are captured again with a graph edge and the line says so (the word
+    is set artificially here: no launch has ever given up on this stack)."""
+    env = dict(os.environ, TT_BENCH_TEST_GAVE_UP="1")
+    env.pop("TT_POLICY_EDGE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                        "--repeats", "1"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "gave up waiting for its image during setup" in r.stderr
+    d = json.loads([x for x in r.stdout.splitlines() if x.strip()][-1])
+    assert d["config"]["policy_image_handover"].startswith("graph edge (fallback")
+    assert 0.02 < d["ms_per_step"] < 1.0 and d["steps"] == 20
