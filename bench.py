@@ -474,7 +474,7 @@ def main():
             dist.all_reduce(per_unit, op=dist.ReduceOp.MIN)
         reps = min(2000, max(1, int(args.settle_ms * 1e-3 / max(float(per_unit.item()), 1e-6))))
         for _ in range(reps):       # a synchronize per unit: hundreds of queued replays leave the runtime resources to reclaim,
-            run(unit)               # and it does that in the next synchronize -- the timed region's (0.3 ms, tools/r03_j.sh)
+            run(unit)               # and it does that in the next synchronize -- the timed region's (0.3 ms; seen with the env workload)
             sync_all()
         settle_steps = unit * (reps + 1)
     extra["setup_vector_steps"] = ddpg_loop.vector_steps if ddpg_loop is not None else settle_steps

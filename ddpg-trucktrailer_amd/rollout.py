@@ -403,7 +403,7 @@ class DDPGRollout:
                     # step's image (weights as learn() of step t-1 left them: the actor is next written by the LAST launch of
                     # this learn()) -- one launch and one dependent boundary less on the learn chain
                     # (a pack launch of its own for the FIRST step of a graph, so that its policy launch starts ~15 us earlier,
-                    # made no measurable difference: 0.0925 ms either way, tools/r03_h.sh)
+                    # made no measurable difference: 0.0925 ms either way on one box)
                     self._learn_all(presampled=False, with_image=True)
             if edge:
                 cur.wait_event(opened)

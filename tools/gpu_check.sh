@@ -1,6 +1,7 @@
 #!/bin/bash
+# GPU box: the whole -m gpu suite, build() + smoke() in one process, and the bench line in the driver form.
 set -o pipefail
-out=gpurun_out/${1:-r03p}
+out=gpurun_out/${1:-gpu_check}
 mkdir -p $out
 timeout -k 10 1100 python3 -m pytest tests -x -q -m gpu > $out/tests.log 2>&1; echo "tests rc=$?" >> $out/tests.log
 tail -5 $out/tests.log
