@@ -78,7 +78,7 @@ class TTSampleArgs(C.Structure):
                 ("obs", C.c_void_p), ("act", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p), ("seed", C.c_uint64),
                 ("side", C.POINTER(TTSideBuffer)), ("s_out", C.c_void_p), ("a_out", C.c_void_p), ("r_out", C.c_void_p),
                 ("s2_out", C.c_void_p), ("d_out", C.c_void_p), ("idx_out", C.c_void_p), ("lag", C.c_int32),
-                ("draws", C.c_int32), ("seed_stride", C.c_uint64)]
+                ("draws", C.c_int32), ("seed_stride", C.c_uint64), ("step_progress", C.c_void_p)]
 
 
 class TTImageJob(C.Structure):

@@ -619,6 +619,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
     bool have_act = false;
     float act_r0 = 0.f, act_r1 = 0.f;
     if (J.sampled) {
+        ttnet::await_progress(J.R.progress, J.R.k_dev);
         const int tid = threadIdx.x, wave = tid >> 6, l15 = tid & 15;
         if (J.k_snapshot && blockIdx.x == 0 && tid == 0) *J.k_snapshot = *J.R.k_dev;
         const bool from_s = q.obs == J.R.s_out;                  // this job reads s (else s')
@@ -1672,6 +1673,7 @@ static int forward_multi_impl(int n, int count, const tt_fwd_job *jobs, const tt
         const int rc = ttnet::make_ring_sample(sample, J.R);
         if (rc != TT_OK) return rc;
         J.sampled = 1;
+        J.R.progress = const_cast<int *>(sample->step_progress);
         J.k_snapshot = reinterpret_cast<long long *>(k_snapshot);
     }
     for (int i = 0; i < count; ++i) {

@@ -330,7 +330,7 @@ static int make_sample(int batch, int n_envs, int slots, const int64_t *k_dev, c
                        float *s_out, float *a_out, float *r_out, float *s2_out, uint8_t *d_out, int32_t *idx_out,
                        RingSample &R) {
     const tt_sample_args a{batch, n_envs, slots, reserve, k_dev, obs, act, rew, done, seed, side, s_out, a_out, r_out, s2_out,
-                           d_out, idx_out, lag, 1, 0};
+                           d_out, idx_out, lag, 1, 0, nullptr};
     return make_ring_sample(&a, R);
 }
 

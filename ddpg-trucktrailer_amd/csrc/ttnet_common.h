@@ -124,6 +124,7 @@ struct RingSample {
     int *idx_out;
     int draws;                         // draws of `batch` rows each in one launch (k_pack_and_sample only; else 1)
     unsigned long long seed_stride;    // draw u uses seed + u * seed_stride
+    int *progress;                     // (k_fwd_multi, sampled) nullptr or the step chain's progress word to wait for (await_progress)
 };
 
 // where batch row b of a draw comes from: a side tuple j (side = true) or ring transition (slot t, env e), t1 = the slot of s'
@@ -201,7 +202,7 @@ inline int make_ring_sample(const tt_sample_args *a, RingSample &R) {
         sb = SideBuf{sd->obs, sd->act, sd->rew, sd->obs2, sd->done, sd->count};
     }
     R = RingSample{a->batch, a->n_envs, a->slots, a->reserve, a->lag, reinterpret_cast<const long long *>(a->k_dev), a->obs, a->act,
-                   a->rew, a->done, a->seed, sb, a->s_out, a->a_out, a->r_out, a->s2_out, a->d_out, a->idx_out, 1, 0ull};
+                   a->rew, a->done, a->seed, sb, a->s_out, a->a_out, a->r_out, a->s2_out, a->d_out, a->idx_out, 1, 0ull, nullptr};
     return TT_OK;
 }
 
@@ -238,7 +239,7 @@ __device__ __forceinline__ void write_cursor(const RingCursor &c) {
 // epoch (relaxed, agent scope, s_sleep between polls, bounded), then agent-scope acquire, wait, workgroup barrier; only then
 // does the workgroup read cursor or image.  Both sides run on every ring-addressed launch; where the two launches are ordered
 // anyway (same stream) the first poll succeeds.
-constexpr int CUR_EPOCH = 12, CUR_ARRIVED = 14, CUR_GAVE_UP = 15;
+constexpr int CUR_EPOCH = 12, CUR_ARRIVED = 14, CUR_GAVE_UP = 15, CUR_PROGRESS = 16;
 constexpr unsigned long long TT_IMAGE_WAIT_TICKS = 25000000ull;      // 0.25 s
 // (Tried: write-through sc1 stores of image and cursor + each wave's wait, no release fence -- cheaper for the pack launch, but
 // tests/test_distributed.py::test_two_rank_loop_graphs_match_eager then saw a stale image on a plain kernel-to-kernel
@@ -283,6 +284,34 @@ __device__ __forceinline__ void await_image(int *cursor, const long long *step_d
     }
     asm volatile("" ::: "memory");
     __syncthreads();
+}
+
+// ---- the other direction: "the step chain has reached step p" = cursor[CUR_PROGRESS] = p + 1, stored by the first workgroup
+// of the policy launch of step p when it starts (everything in front of it on its stream -- the env step of step p - 1 -- is
+// then over and written back).  The first launch of a pipelined learn() waits for progress >= its window counter instead of for a
+// graph edge from that env step (3.4 us of every 92 us step at N = 65536: the wait packet of an edge that was always
+// satisfied).  Same protocol and limits as await_image; progress points at cursor + CUR_PROGRESS.
+__device__ __forceinline__ void await_progress(int *progress, const long long *k_dev) {          // every thread of the block
+    if (!progress) return;
+    if (threadIdx.x == 0) {
+        const int want = (int)*k_dev;
+        if (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+                __builtin_amdgcn_s_sleep(32);
+                if (wall_clock64() - t0 > TT_IMAGE_WAIT_TICKS) {
+                    __hip_atomic_store(progress - CUR_PROGRESS + CUR_GAVE_UP, want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    asm volatile("" ::: "memory");
+    __syncthreads();
+    // (the acquire leaves the SCALAR cache alone -- DESIGN.md section 4.2 (i) -- but nothing the step chain writes is read through
+    // it here: the ring's rows come by vector loads, the window counter is the learn chain's own)
 }
 
 // csrc/ttnet_split.hip

@@ -173,6 +173,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
         obs_base = resolve_obs(act, obs);
         load_obs(tile);
     }
+    if (act.cursor && tile0 == 0 && blockIdx.x == 0 && tid == 0)      // this launch has begun: the step chain is at step kstep
+        __hip_atomic_store(act.cursor + CUR_PROGRESS, (int)(kstep + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (act.cursor && tile0 == 0 && blockIdx.x == 0 && tid < 4) {
         const int sl = act.ring_slots;
         act.cursor[tid] = !local ? cursor_of(act)[tid]

@@ -75,7 +75,8 @@ class TrajectoryRing:
         # (include/ttenv.h: tt_ring_view / tt_ring_cursor) so that captured launches need no per-position pointers
         # [4..7] / [8..11]: the cursors {t, t+1, t-1, t > 0} of even / odd steps, [0..3]: the running step's (include/ttenv.h)
         # ring cursors [0..11] + the image hand-over words [12..15] (include/ttenv.h: TT_CURSOR_INTS)
-        self.cursor_dev = torch.zeros(16, dtype=torch.int32, device=device)
+        # [16]: the step chain's progress (k + 1 once the policy launch of step k has begun): what a pipelined learn() waits for
+        self.cursor_dev = torch.zeros(32, dtype=torch.int32, device=device)
 
     def attach(self, env):
         """Let the env's step kernel advance k_dev (tt_env_set_step_counter): one launch less per vector step.  From
@@ -162,6 +163,7 @@ class TrajectoryRing:
         self.k = int(sd["k"])               # the counters come back whether or not the contents did
         self.k_dev.fill_(self.k)
         self.cursor_dev.zero_()             # image epochs are step numbers: a counter set back must not find newer ones
+        self.cursor_dev[16] = self.k        # ... and the step chain is where the counters say (TT_CURSOR_PROGRESS)
 
     def policy_gave_up(self):
         """Step number + 1 at which a policy launch stopped waiting for its image (include/ttenv.h: TT_CURSOR_GAVE_UP), 0 = never.
@@ -193,10 +195,12 @@ class TrajectoryRing:
         self._bufs = cache[batch_size]          # (the set of the latest draw)
         return self._bufs
 
-    def sample_args(self, batch_size, seed=0, k_dev=None, reserve=0, lag=0, draws=1, seed_stride=0):
+    def sample_args(self, batch_size, seed=0, k_dev=None, reserve=0, lag=0, draws=1, seed_stride=0, wait_for_steps=False):
         """tt_sample_args for one draw into the ring's batch buffers (include/ttenv.h); keeps what it points at alive.
         draws > 1 (tt_mlp_split_pack_and_sample only): that many draws of batch_size rows, draw u with seed + u * seed_stride
-        into rows [u * batch_size, (u + 1) * batch_size) of the buffers _batch_bufs(draws * batch_size)."""
+        into rows [u * batch_size, (u + 1) * batch_size) of the buffers _batch_bufs(draws * batch_size).
+        wait_for_steps (tt_mlp_forward_multi_sampled only): the launch first waits, in device memory, until the step chain has
+        reached step *k_dev - 1 (cursor word 16, written by every ring-addressed policy launch): tt_sample_args.step_progress."""
         from ddpg_trucktrailer_amd import _lib as L
         s, a, r, s2, dn, idx = self._batch_bufs(batch_size * max(1, int(draws)))
         p = lambda t: t.data_ptr()
@@ -206,7 +210,8 @@ class TrajectoryRing:
         return L.TTSampleArgs(batch_size, self.n, self.slots, int(reserve), p(self.k_dev if k_dev is None else k_dev),
                               p(self.obs), p(self.act), p(self.rew), p(self.done), int(seed) & (2 ** 64 - 1),
                               C.pointer(side) if side is not None else None, p(s), p(a), p(r), p(s2), p(dn), p(idx), int(lag),
-                              max(1, int(draws)), int(seed_stride) & (2 ** 64 - 1))
+                              max(1, int(draws)), int(seed_stride) & (2 ** 64 - 1),
+                              self.cursor_dev.data_ptr() + 4 * 16 if wait_for_steps else None)
 
     def sample_fused(self, batch_size, seed=0, return_index=False, done_as_bool=True, k_dev=None, reserve=0, lag=0):
         """sample() as ONE HIP launch (tt_ring_sample): Philox indices keyed by (seed, k_dev) + gather.

@@ -44,6 +44,7 @@ from ddpg_trucktrailer_amd.replay_buffer import TrajectoryRing
 # every launch of a capture comes from the capturing thread; "thread_local" keeps another thread's runtime calls (the
 # collective library's watchdog, a data loader) from invalidating it
 _CAPTURE_MODE = "thread_local"
+_LEARN_EDGE_EVERY = 4                    # pipelined graphs: steps between graph edges from the step chain into the learn chain
 _SEED_STRIDE = 0x9E3779B97F4A7C15     # sampling key of update u of a vector step = seed + u * stride (mod 2^64)
 # Pipelined order: learn() of vector step t draws from the steps up to t-2 (lag 1: step t-1 may still be under way beside the
 # draw) and keeps off the two observation rows the env steps t-1 and t write meanwhile (reserve 2)
@@ -181,7 +182,7 @@ class DDPGRollout:
         cur = L.TTRingCursor(self._k_snap_dev.data_ptr(), self.ring.slots, 0, self.ring.cursor_dev.data_ptr())
         return (w, cur, self._k_snap_dev)
 
-    def _learn_once(self, u=0, presampled=False, with_image=False):
+    def _learn_once(self, u=0, presampled=False, with_image=False, wait_for_steps=False):
         sample = None
         if presampled:         # the step's opening launch already drew this batch into the ring's buffers
             B, draws = self.batch_size, self._draws_per_opening()
@@ -191,7 +192,7 @@ class DDPGRollout:
             # _sample(u), one launch less per update
             if self.pipeline:
                 sample = self.ring.sample_args(self.batch_size, seed=self._sample_key(u), k_dev=self.k_pipe_dev,
-                                               reserve=_PIPE_RESERVE, lag=_PIPE_LAG)
+                                               reserve=_PIPE_RESERVE, lag=_PIPE_LAG, wait_for_steps=wait_for_steps)
             else:
                 sample = self.ring.sample_args(self.batch_size, seed=self._sample_key(u))
             s, a, r, s2, d = self.ring._batch_bufs(self.batch_size)[:5]
@@ -214,10 +215,10 @@ class DDPGRollout:
                  and self.device.type == "cuda" and os.environ.get("TT_MULTI_DRAW", "1") == "1")
         return self.updates_per_step if multi else 1
 
-    def _learn_all(self, presampled=False, with_image=False):
+    def _learn_all(self, presampled=False, with_image=False, wait_for_steps=False):
         draws = self._draws_per_opening() if presampled else 1
         for u in range(self.updates_per_step):
-            self._learn_once(u, presampled and u < draws, with_image and u == 0)
+            self._learn_once(u, presampled and u < draws, with_image and u == 0, wait_for_steps and u == 0)
 
     def learn(self):
         if self.ring.k < 2:
@@ -391,7 +392,8 @@ class DDPGRollout:
         edge = self.policy_edge() == "graph"
         for t in range(steps):
             with torch.cuda.stream(side):
-                if t >= 2:
+                # (without the hand-over through device memory: every step; with it: every _LEARN_EDGE_EVERY-th step, see below)
+                if t >= 2 and (edge or t % _LEARN_EDGE_EVERY == 0):
                     side.wait_event(stepped[t - 2])
                 if edge:
                     self._open_step(True)
@@ -404,7 +406,16 @@ class DDPGRollout:
                     # this learn()) -- one launch and one dependent boundary less on the learn chain
                     # (a pack launch of its own for the FIRST step of a graph, so that its policy launch starts ~15 us earlier,
                     # made no measurable difference: 0.0925 ms either way on one box)
-                    self._learn_all(presampled=False, with_image=True)
+                    # ... and B(t) after the env step of t-2, through device memory as well: its first launch waits for the step
+                    # chain's progress word (the policy launch of step t-1 has begun: include/ttenv.h, TT_CURSOR_PROGRESS) -- the
+                    # wait packet of that graph edge, always satisfied, cost 3.4 us of every step (0.0923 -> 0.0889 ms).
+                    # One step in _LEARN_EDGE_EVERY keeps the edge all the same (redundant as an ordering): a graph of two
+                    # chains with NO edge between them starts 0.2 ms late when it is launched into an idle GPU (one 20-step
+                    # replay after a synchronize -- the driver's timed region: 0.1005 ms per step against 0.0894 back to
+                    # back; presumably the runtime submits such a graph chain after chain, and the policy launch waits for a
+                    # learn chain whose packets are still on their way).  With an edge every 3rd..6th step: 0.088-0.092 for
+                    # the single replay, 0.089-0.090 back to back (tools/driver_form.py).
+                    self._learn_all(presampled=False, with_image=True, wait_for_steps=True)
             if edge:
                 cur.wait_event(opened)
             self._act_and_step()

@@ -163,7 +163,7 @@ int tt_env_step(tt_env *env, const float *action, float *obs, float *reward, uin
  * tt_ring_cursor of tt_mlp_split_pack[_and_sample]).  Launches that take a view read / write the step's slots through the
  * cursor instead of through per-slot pointers, so ONE captured hipGraph serves every ring position. */
 typedef struct tt_ring_view {
-    int32_t *cursor;        /* [16] device ([12..15]: the image hand-over words, below): [4..7] / [8..11] the cursors of even / odd steps (written by the opening launch of
+    int32_t *cursor;        /* [TT_CURSOR_INTS] device ([12..16]: the hand-over words, below): [4..7] / [8..11] the cursors of even / odd steps (written by the opening launch of
                                the step), [0..3] the running step's copy, left by tt_actor_act_ring for tt_env_step_ring */
     float *obs, *act, *rew;
     uint8_t *done;
@@ -172,7 +172,7 @@ typedef struct tt_ring_view {
 typedef struct tt_ring_cursor {
     const int64_t *k_dev;   /* vector steps completed (tt_env_set_step_counter); nothing may advance it beside the launch */
     int32_t slots, reserved_;
-    int32_t *cursor;        /* [16] device (tt_ring_view): the launch writes the four numbers of step *k_dev at [4 + 4 (k & 1)] */
+    int32_t *cursor;        /* [TT_CURSOR_INTS] device (tt_ring_view): the launch writes the four numbers of step *k_dev at [4 + 4 (k & 1)] */
 } tt_ring_cursor;
 /* Image hand-over (cursor[12..15], zero-initialised by the caller, re-zeroed when *k_dev is set back): a pack launch given a
  * cursor ends by publishing "cursor and image of step k = *k_dev are complete" as cursor[12 + (k & 1)] = k + 1 (release,
@@ -180,8 +180,14 @@ typedef struct tt_ring_cursor {
  * after 0.25 s it sets cursor[15] = k + 1 and goes on -- TT_CURSOR_GAVE_UP; a caller that lets the two launches run
  * unordered checks that word).  The two launches of a step therefore need NO stream / graph dependency between them; the
  * pack launch of step k + 2, which overwrites the same image, must still be ordered behind the policy launch of step k. */
-#define TT_CURSOR_INTS 16
+#define TT_CURSOR_INTS 32
 #define TT_CURSOR_GAVE_UP 15
+/* Step-chain progress (cursor[16]): tt_actor_act_ring of step k begins by storing k + 1 there (device scope).  A launch starts
+ * only when everything in front of it on its stream is complete and written back, so cursor[16] >= k + 1 says: the env step of
+ * step k - 1 -- and every launch before it -- is over and visible.  tt_mlp_forward_multi_sampled can wait for that word instead of
+ * for a stream / graph dependency on the env step (tt_sample_args.step_progress), so that a loop's learn chain needs no edge
+ * from its step chain either.  The caller sets the word to *k_dev whenever it sets *k_dev (resume). */
+#define TT_CURSOR_PROGRESS 16
 /* tt_env_step with obs -> ring slot t+1, reward and done -> slot t (env.step of the vector loop, trainv2.py:520-525). */
 int tt_env_step_ring(tt_env *env, const float *action, const tt_ring_view *ring, int auto_reset, tt_stream_t stream);
 
@@ -331,6 +337,10 @@ typedef struct tt_sample_args {
                               * vector step (each of them exactly what its own tt_ring_sample with that seed would draw), so that
                               * none of them has the ring's latency on its chain.  Other entry points take one draw and ignore it */
     uint64_t seed_stride;
+    const int32_t *step_progress; /* tt_mlp_forward_multi_sampled only; NULL or the ring's cursor + TT_CURSOR_PROGRESS: the launch then first
+                              * waits until *step_progress >= *k_dev -- the env step whose transitions close the draw's window is over
+                              * (k_dev must then be a counter that runs `lag` ahead of the steps completed, as a pipelined loop's does);
+                              * bounded like the image hand-over, same give-up word (cursor[TT_CURSOR_GAVE_UP]) */
 } tt_sample_args;
 int tt_mlp_split_pack_and_sample(const tt_mlp_weights *w, int critic, void *ws, const tt_sample_args *sample,
                                  const tt_ring_cursor *cursor, tt_stream_t stream);
