@@ -488,7 +488,7 @@ def main():
     # a launch that left by its time limit -- it never has on this stack (tests at this graph length, 200 k-step soaks), but which
     # hardware queue the runtime gives a graph's chain is not a promise -- means the chains did not run beside each other.
     # Seen BEFORE the timed region it costs the run nothing but the hand-over: the graphs are captured again with a graph edge
-    # (0.096 instead of 0.092 ms per step), and the line says so.  Inside the timed region it fails the run (below).
+    # (0.095 instead of 0.089 ms per step), and the line says so.  Inside the timed region it fails the run (below).
     handover_fallback = False
     if ddpg_loop is not None and ddpg_loop.ring_mode and ddpg_loop.graph_steps and ddpg_loop.policy_edge() == "flag":
         if os.environ.get("TT_BENCH_TEST_GAVE_UP") == "1":      # (tests/test_gpu_bench_line.py: the fallback below must work)
