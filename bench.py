@@ -494,8 +494,8 @@ def main():
         if os.environ.get("TT_BENCH_TEST_GAVE_UP") == "1":      # (tests/test_gpu_bench_line.py: the fallback below must work)
             ddpg_loop.ring.cursor_dev[15] = 1
         if ddpg_loop.ring.policy_gave_up():
-            print("bench.py: a policy launch gave up waiting for its image during setup; capturing the steps again with a graph "
-                  "edge into the policy launch (TT_POLICY_EDGE=graph)", file=sys.stderr, flush=True)
+            print("bench.py: a launch gave up waiting for the other chain of its step during setup; capturing the steps again with graph "
+                  "edges between the chains (TT_POLICY_EDGE=graph)", file=sys.stderr, flush=True)
             wd.enter("prepare again (graph edge)")
             os.environ["TT_POLICY_EDGE"] = "graph"
             handover_fallback = True
@@ -598,10 +598,10 @@ def main():
             "f32_mfma_peak_tflops": 157.3}
     if ddpg_loop is not None and ddpg_loop.ring_mode:
         gave_up = ddpg_loop.ring.policy_gave_up()      # (device-memory hand-over of the policy image: include/ttenv.h)
-        assert gave_up == 0, f"a policy launch gave up waiting for the image of step {gave_up - 1}"
+        assert gave_up == 0, f"a launch gave up waiting for the other chain of its step (step {gave_up - 1}): policy for its image, or learn() for the env step"
         out["config"]["policy_image_handover"] = ("graph edge" if ddpg_loop.policy_edge() == "graph" else "device memory (epoch word)")
         if handover_fallback:
-            out["config"]["policy_image_handover"] += " (fallback: a policy launch gave up waiting during setup)"
+            out["config"]["policy_image_handover"] += " (fallback: a launch gave up waiting during setup)"
     if ar_us is not None:
         out["allreduce_us"] = ar_us
     if rank == 0:

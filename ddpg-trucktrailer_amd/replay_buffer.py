@@ -166,7 +166,8 @@ class TrajectoryRing:
         self.cursor_dev[16] = self.k        # ... and the step chain is where the counters say (TT_CURSOR_PROGRESS)
 
     def policy_gave_up(self):
-        """Step number + 1 at which a policy launch stopped waiting for its image (include/ttenv.h: TT_CURSOR_GAVE_UP), 0 = never.
+        """Step number + 1 at which a launch stopped waiting for the other chain -- a policy launch for its image, or learn()'s first
+        launch for the step chain's progress (include/ttenv.h: TT_CURSOR_GAVE_UP, TT_CURSOR_PROGRESS) --, 0 = never.
         Synchronises."""
         return int(self.cursor_dev[15].item())
 

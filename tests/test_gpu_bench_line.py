@@ -53,7 +53,7 @@ def test_fallback_to_a_graph_edge_when_a_policy_launch_gave_up_in_setup(gpu_devi
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
                         "--repeats", "1"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert "gave up waiting for its image during setup" in r.stderr
+    assert "gave up waiting for the other chain of its step during setup" in r.stderr
     d = json.loads([x for x in r.stdout.splitlines() if x.strip()][-1])
     assert d["config"]["policy_image_handover"].startswith("graph edge (fallback")
     assert 0.02 < d["ms_per_step"] < 1.0 and d["steps"] == 20
