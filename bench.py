@@ -487,25 +487,24 @@ def main():
     # The policy launch of a captured step waits for its image in device memory (include/ttenv.h: image hand-over), bounded:
     # a launch that left by its time limit -- it never has on this stack (tests at this graph length, 200 k-step soaks), but which
     # hardware queue the runtime gives a graph's chain is not a promise -- means the chains did not run beside each other.
-    # Seen BEFORE the timed region it costs the run nothing but the hand-over: the graphs are captured again with a graph edge
-    # (0.095 instead of 0.089 ms per step), and the line says so.  Inside the timed region it fails the run (below).
+    # DDPGRollout.run() notices that itself (a host-visible mirror of the give-up word, looked at after every replay), captures
+    # the steps again with graph edges (0.095 instead of 0.089 ms per step) and goes on; a second time it raises.  Seen BEFORE the
+    # timed region it costs the run nothing but the hand-over, and the line says so.  Inside the timed region it fails the run.
     handover_fallback = False
     if ddpg_loop is not None and ddpg_loop.ring_mode and ddpg_loop.graph_steps and ddpg_loop.policy_edge() == "flag":
         if os.environ.get("TT_BENCH_TEST_GAVE_UP") == "1":      # (tests/test_gpu_bench_line.py: the fallback below must work)
-            ddpg_loop.ring.cursor_dev[15] = 1
-        if ddpg_loop.ring.policy_gave_up():
-            print("bench.py: a launch gave up waiting for the other chain of its step during setup; capturing the steps again with graph "
-                  "edges between the chains (TT_POLICY_EDGE=graph)", file=sys.stderr, flush=True)
+            ddpg_loop.ring.mark_gave_up_for_test(ddpg_loop.ring.k - 1)
+        if ddpg_loop._check_handover(exact=True) or ddpg_loop.handover_gave_up:
+            print("bench.py: a launch gave up waiting for the other chain of its step during setup; the steps are captured again with graph "
+                  "edges between the chains (as TT_POLICY_EDGE=graph does)", file=sys.stderr, flush=True)
             wd.enter("prepare again (graph edge)")
-            os.environ["TT_POLICY_EDGE"] = "graph"
             handover_fallback = True
-            ddpg_loop.ring.cursor_dev[15] = 0
-            ddpg_loop.invalidate_graphs()
             ddpg_loop.prepare()
             ddpg_loop.first_launches()
             run(max(args.warmup, ddpg_loop.graph_steps))
             sync_all()
             extra["setup_vector_steps"] = ddpg_loop.vector_steps
+    gave_up_in_setup = len(ddpg_loop.handover_gave_up) if ddpg_loop is not None else 0
     wd.enter("timed region")
     captured = graph_k > 1 or (ddpg_loop is not None and ddpg_loop.graph_steps > 0)
     if not captured:
@@ -598,7 +597,9 @@ def main():
             "f32_mfma_peak_tflops": 157.3}
     if ddpg_loop is not None and ddpg_loop.ring_mode:
         gave_up = ddpg_loop.ring.policy_gave_up()      # (device-memory hand-over of the policy image: include/ttenv.h)
-        assert gave_up == 0, f"a launch gave up waiting for the other chain of its step (step {gave_up - 1}): policy for its image, or learn() for the env step"
+        late = ddpg_loop.handover_gave_up[gave_up_in_setup:]
+        assert gave_up == 0 and not late, (f"a launch gave up waiting for the other chain of its step (step {(gave_up or late[0]) - 1}) in or "
+                                           "after the timed region: policy for its image, or learn() for the env step")
         out["config"]["policy_image_handover"] = ("graph edge" if ddpg_loop.policy_edge() == "graph" else "device memory (epoch word)")
         if handover_fallback:
             out["config"]["policy_image_handover"] += " (fallback: a launch gave up waiting during setup)"

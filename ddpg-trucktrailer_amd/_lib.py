@@ -108,6 +108,7 @@ _SIGNATURES = {
     "tt_env_set_state": (C.c_int, [_P, _P, _I, _P, _P]),
     "tt_env_get_state": (C.c_int, [_P, _P, _P]),
     "tt_env_set_max_steps": (C.c_int, [_P, _P, _I, _P, _P]),
+    "tt_env_set_steps": (C.c_int, [_P, _P, _I, _P, _P]),
     "tt_env_get_episode": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "tt_env_observe": (C.c_int, [_P, _P, _P, _P]),
     "tt_env_set_step_counter": (C.c_int, [_P, _P]),

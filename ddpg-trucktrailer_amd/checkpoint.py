@@ -68,10 +68,19 @@ def load_training_checkpoint(path, agent, env=None, ring=None, noise=None):
     return ck.get("training_state", {})
 
 
-def save_loop_checkpoint(path, loop, training_state=None):
+def save_loop_checkpoint(path, loop, training_state=None, force=False):
     """The whole N-env loop (DDPGRollout.state_dict: networks, Adam state, env batch, replay ring + side buffer, OU state,
-    counters) in one file; a loop restored from it continues bit for bit (tests/test_gpu_rollout.py)."""
-    torch.save({"format": 2, "loop": loop.state_dict(), "training_state": training_state or {}}, path)
+    counters) in one file; a loop restored from it continues bit for bit (tests/test_gpu_rollout.py).
+    Refuses (RuntimeError, nothing written) a loop in which a launch gave up waiting for the other chain of its step: that
+    step acted on a stale policy image or drew from rows still being written (DDPGRollout._check_handover); force=True
+    saves it all the same, with the steps listed under "handover_gave_up"."""
+    sd = loop.state_dict()                 # (synchronises and looks at the give-up word)
+    if sd.get("handover_gave_up") and not force:
+        steps = ", ".join(str(x - 1) for x in sd["handover_gave_up"])
+        raise RuntimeError(f"not saving {path}: a launch of vector step(s) {steps} gave up waiting for the other chain of its step and "
+                           "went on with stale inputs, so this loop's state is not what the reference's order of operations "
+                           "(trainv2.py:511-531) produces; pass force=True to save it anyway")
+    torch.save({"format": 2, "loop": sd, "training_state": training_state or {}}, path)
     return path
 
 

@@ -67,12 +67,20 @@ enum HotRow : int {
 // cold SoA rows [C_ROWS][npad]
 enum ColdRow : int { C_SX = 0, C_SY, C_SYAW, C_GX, C_GY, C_GYAW, C_SG, C_CG, C_L2, C_ROWS };
 
-// packed per-env counters: steps [0,12) | max_episode_steps [12,24) | stages_achieved [24,27)
+// packed per-env counters: steps [0,12) | max_episode_steps [12,24) | stage latches 2, 3 [24,26) | carry age [26,32)
+//   steps      env.episode_steps (simv2.py:523-525): what the exploration tiers, the max-step penalty and the max-steps flag read;
+//              a caller may write it (tt_env_set_steps; episode_replay_collectorv2.py:269) WITHOUT touching the reward carry;
+//   stages     stages_achieved[1], [2] of the reward carry (reward_functionv1.py:338-367); [0] is written but never read (Q2:
+//              the stage-1 bonus is paid on every step inside 5 m), so it is not kept;
+//   carry age  step_count_for_backward_tracking of the reward carry (:57-60, :258), saturating at 63 -- only min(1, n / 50) is
+//              read (:263) -- and 0 <=> `reward_state is None` (simv2.py:349): the next step builds the carry afresh.
 __host__ __device__ inline uint32_t pk_steps(uint32_t p) { return p & 0xFFFu; }
 __host__ __device__ inline uint32_t pk_max(uint32_t p) { return (p >> 12) & 0xFFFu; }
-__host__ __device__ inline uint32_t pk_stages(uint32_t p) { return (p >> 24) & 0x7u; }
-__host__ __device__ inline uint32_t pk_make(uint32_t steps, uint32_t maxs, uint32_t stages) {
-    return (steps > 0xFFFu ? 0xFFFu : steps) | ((maxs > 0xFFFu ? 0xFFFu : maxs) << 12) | ((stages & 7u) << 24);
+__host__ __device__ inline uint32_t pk_stages(uint32_t p) { return (p >> 24) & 0x3u; }
+__host__ __device__ inline uint32_t pk_age(uint32_t p) { return p >> 26; }
+__host__ __device__ inline uint32_t pk_make(uint32_t steps, uint32_t maxs, uint32_t stages, uint32_t age) {
+    return (steps > 0xFFFu ? 0xFFFu : steps) | ((maxs > 0xFFFu ? 0xFFFu : maxs) << 12) | ((stages & 3u) << 24) |
+           ((age > 63u ? 63u : age) << 26);
 }
 
 // numeric constants of the kernel's polynomials and of the RK45 tableau
@@ -394,8 +402,8 @@ __device__ inline void place_env(const KParams &P, const Bufs &b, int i, Env &e,
     e.dinit = sqrt(ddx * ddx + ddy * ddy);
     e.g = g; e.gyaw = gyaw; e.L2 = L2;
     const int maxs = P.fixed_max > 0 ? P.fixed_max : (int)(e.dinit / P.step_length) + P.extra_steps;
-    e.pk = pk_make(0u, (uint32_t)maxs, 0u);
-    // carry rows are re-initialised by the first step (steps == 0); keep them finite
+    e.pk = pk_make(0u, (uint32_t)maxs, 0u, 0u);
+    // carry rows are re-initialised by the first step (carry age 0); keep them finite
     e.d3 = e.d2 = e.d1 = e.prev = e.closest = e.dinit; e.cum = 0.0; e.psteer = 0.0f;
     hot_ptr(b.hot, i)[H_DINIT * TILE] = e.dinit;  // read-only for the step kernel: store_env() does not write it
     double *c = b.cold + i;
@@ -506,7 +514,8 @@ __device__ __forceinline__ void step_env(const KParams &P, Env &e, float action,
     // The reward's three tanh -- dynamic weights (:189-238): tanh(7(jp - 0.3)); progress (:144-187):
     // tanh(prev - cur), tanh((hist[0] - cur)/2) -- are (1 - t)/(1 + t), t = exp(-2|x|).  Two of them, 1/cur
     // and 1/init share ONE division through the product of the denominators.
-    const bool first = pk_steps(pk) == 0u || P.stateless != 0;  // reward_state is None (:40-76)
+    const bool first = pk_age(pk) == 0u || P.stateless != 0;  // reward_state is None (:40-76)
+    const uint32_t age = first ? 1u : pk_age(pk) + 1u;         // step_count_for_backward_tracking after this step (:258)
     const double prev = first ? cur : e.prev, d3 = first ? cur : e.d3, d1 = first ? cur : e.d1;
     const double inst = prev - cur;
     const double net = (d3 - cur) * 0.5;
@@ -566,10 +575,10 @@ __device__ __forceinline__ void step_env(const KParams &P, Env &e, float action,
         const double oa = tt_wrap_pi(T, e.gyaw - e.psi2);
         const double ori_err = (double)fabsf(tt_atan2_readback(oa, e.g.sg * c2 - e.g.cg * s2, e.g.cg * c2 + e.g.sg * s2,
                                                                of[19], of[20]));
-        if (cur <= 5.0) { staged += 10.0; stages |= 1u; }
-        if (cur <= 2.0 && ori_err <= 45.0 * kDeg && !(stages & 2u)) { staged += 25.0; stages |= 2u; }
+        if (cur <= 5.0) staged += 10.0;   // every step, no latch (Q2)
+        if (cur <= 2.0 && ori_err <= 45.0 * kDeg && !(stages & 1u)) { staged += 25.0; stages |= 1u; }
         at_goal = cur <= P.pos_thr && ori_err <= P.ori_thr;
-        if (at_goal && !(stages & 4u)) { staged += 100.0; stages |= 4u; }
+        if (at_goal && !(stages & 2u)) { staged += 100.0; stages |= 2u; }
     }
     // safety (:369-421)
     double safety = 0.0;
@@ -593,7 +602,7 @@ __device__ __forceinline__ void step_env(const KParams &P, Env &e, float action,
     const double explore = (double)steps < rmax * 0.5 ? 4.0 : ((double)steps < rmax * 0.8 ? 2.0 : 0.0);
     // backward-movement budget (:240-283)
     e.cum += fmax(0.0, cur - prev);
-    const double budget = 5.0 * fmin(1.0, (double)(P.stateless ? 1u : steps) * 0.02);  // step_count_for_backward_tracking
+    const double budget = 5.0 * fmin(1.0, (double)age * 0.02);  // step_count_for_backward_tracking (stateless: always 1)
     const double excess = fmax(0.0, e.cum - budget);
     double back = 0.0;
     if (__any(excess > 0.0)) back = excess > 0.0 ? -(excess * sqrt(excess)) * 0.5 : 0.0;
@@ -619,7 +628,7 @@ __device__ __forceinline__ void step_env(const KParams &P, Env &e, float action,
 
     // carry for the next step: window [hist1..hist4] <- [hist2, hist3, hist4, cur]
     e.d3 = first ? cur : e.d2; e.d2 = d1; e.d1 = prev; e.prev = cur;
-    e.pk = pk_make(steps, pk_max(pk), stages);
+    e.pk = pk_make(steps, pk_max(pk), stages, age);
 }
 
 __device__ __forceinline__ void write_info(const Info &info, size_t N, int i, const Env &e, const StepOut &o) {
@@ -845,7 +854,20 @@ __global__ __launch_bounds__(BLOCK) void k_set_max_steps(const int n, const Bufs
     if (i < 0 || i >= n) return;
     uint2 *m = reinterpret_cast<uint2 *>(hot_ptr(b.hot, i) + H_MISC * TILE);
     const uint32_t p = m->y;
-    m->y = pk_make(pk_steps(p), (uint32_t)(maxs[j] < 0 ? 0 : maxs[j]), pk_stages(p));
+    m->y = pk_make(pk_steps(p), (uint32_t)(maxs[j] < 0 ? 0 : maxs[j]), pk_stages(p), pk_age(p));
+}
+
+// `env.episode_steps = k` (simv2.py:94; episode_replay_collectorv2.py:269): the step counter alone -- the reward carry, its
+// age and the stage latches stay (the reference keeps them in reward_state, which such a write does not touch)
+__global__ __launch_bounds__(BLOCK) void k_set_steps(const int n, const Bufs b, const int32_t *idx, const int k,
+                                                     const int32_t *steps) {
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= k) return;
+    const int i = idx ? idx[j] : j;
+    if (i < 0 || i >= n) return;
+    uint2 *m = reinterpret_cast<uint2 *>(hot_ptr(b.hot, i) + H_MISC * TILE);
+    const uint32_t p = m->y;
+    m->y = pk_make((uint32_t)(steps[j] < 0 ? 0 : steps[j]), pk_max(p), pk_stages(p), pk_age(p));
 }
 
 __global__ __launch_bounds__(BLOCK) void k_get_episode(const KParams P, const int n, const Bufs b, int32_t *steps,
@@ -1203,6 +1225,26 @@ int tt_env_set_max_steps(tt_env *env, const int32_t *idx, int k, const int32_t *
                             TT_MAX_EPISODE_STEPS);
     }
     hipLaunchKernelGGL(k_set_max_steps, dim3(grid_for(k)), dim3(BLOCK), 0, stream, env->n, env->b, idx, k, max_steps);
+    TT_HIP(env, hipGetLastError());
+    return TT_OK;
+}
+
+int tt_env_set_steps(tt_env *env, const int32_t *idx, int k, const int32_t *steps, tt_stream_t stream) {
+    if (!env) return fail(nullptr, TT_EINVAL, "tt_env_set_steps: NULL handle");
+    if (k < 0 || k > env->n || (k > 0 && !steps))
+        return fail(env, TT_EINVAL, "tt_env_set_steps: k=%d outside [0,%d] or steps NULL", k, env->n);
+    if (k == 0) return TT_OK;
+    TT_HIP(env, hipSetDevice(env->device));
+    {   // 12-bit packed counter, as for tt_env_set_max_steps: refuse instead of clamping (a setter, not a hot call)
+        std::vector<int32_t> host((size_t)k);
+        TT_HIP(env, hipMemcpyAsync(host.data(), steps, sizeof(int32_t) * (size_t)k, hipMemcpyDeviceToHost, stream));
+        TT_HIP(env, hipStreamSynchronize(stream));
+        for (int j = 0; j < k; ++j)
+            if (host[(size_t)j] < 0 || host[(size_t)j] > TT_MAX_EPISODE_STEPS)
+                return fail(env, TT_EINVAL, "tt_env_set_steps: steps[%d] = %d outside [0, %d]", j, host[(size_t)j],
+                            TT_MAX_EPISODE_STEPS);
+    }
+    hipLaunchKernelGGL(k_set_steps, dim3(grid_for(k)), dim3(BLOCK), 0, stream, env->n, env->b, idx, k, steps);
     TT_HIP(env, hipGetLastError());
     return TT_OK;
 }

@@ -239,11 +239,19 @@ __device__ __forceinline__ void write_cursor(const RingCursor &c) {
 // epoch (relaxed, agent scope, s_sleep between polls, bounded), then agent-scope acquire, wait, workgroup barrier; only then
 // does the workgroup read cursor or image.  Both sides run on every ring-addressed launch; where the two launches are ordered
 // anyway (same stream) the first poll succeeds.
-constexpr int CUR_EPOCH = 12, CUR_ARRIVED = 14, CUR_GAVE_UP = 15, CUR_PROGRESS = 16;
+constexpr int CUR_EPOCH = 12, CUR_ARRIVED = 14, CUR_GAVE_UP = 15, CUR_PROGRESS = 16, CUR_GAVE_UP_MIRROR = 18;
 constexpr unsigned long long TT_IMAGE_WAIT_TICKS = 25000000ull;      // 0.25 s
 // (Tried: write-through sc1 stores of image and cursor + each wave's wait, no release fence -- cheaper for the pack launch, but
 // tests/test_distributed.py::test_two_rank_loop_graphs_match_eager then saw a stale image on a plain kernel-to-kernel
 // boundary: kept to plain stores + ONE agent-scope release per workgroup.)
+// A launch that gives up marks cursor[CUR_GAVE_UP] and, when the caller left the address of a word of device-visible HOST memory in
+// cursor[CUR_GAVE_UP_MIRROR .. + 1] (64 bits, 0 = none), that word as well (system scope): the host can then see the mark by reading
+// its own memory -- no copy, no synchronize in the loop (DDPGRollout.run checks it after every graph replay).
+__device__ __forceinline__ void mark_gave_up(int *cursor, const int value) {
+    __hip_atomic_store(cursor + CUR_GAVE_UP, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int *mirror = *reinterpret_cast<int *const *>(cursor + CUR_GAVE_UP_MIRROR);
+    if (mirror) __hip_atomic_store(mirror, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ void publish_image(const RingCursor &c, const int workgroups) {      // every thread of the block
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -264,9 +272,15 @@ __device__ __forceinline__ void await_image(int *cursor, const long long *step_d
         const long long k = *step_dev;
         const int want = (int)(k + 1);
         const int *flag = cursor + CUR_EPOCH + (int)(k & 1);
-        // Fast path (what a loop in step sees): the epoch is already there.  It was then published before this launch began,
-        // whose own start invalidated this CU's caches, and nothing of the image has been read since: no acquire is needed on
-        // top of the launch's (a fence here costs ~1.7 us on the critical path of every policy launch).
+        // Fast path (what a loop in step sees): the epoch is already there and no acquire is executed (a fence here costs ~1.7 us on
+        // the critical path of every policy launch).  INVARIANT this relies on: between the BEGIN of this dispatch -- whose
+        // acquire invalidated every L1 and the non-local lines of every XCD's L2 -- and the publish of the epoch, NOTHING on the
+        // device reads the image / cursor pair of this parity: this launch's own workgroups read it only after they have seen the
+        // epoch (here), a workgroup that had to wait acquires below before it reads, and the only other reader of this parity's
+        // image is the policy launch of step k - 2, which is over before the pack of step k starts (the step chain's progress
+        // word orders that).  So also a workgroup that starts late and finds an epoch that was published in the middle of this
+        // dispatch meets no line of the image that was cached before the publish.  The pack launch of step k + 2 is the next
+        // writer.  Checked by the 1500-step bitwise test and the soaks (tools/soak.py), not provable from here.
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
             // (one poll per ~3 us and workgroup: 171 workgroups polling one word every 0.1 us slowed the very launches they
             // were waiting for -- seen under rocprofv3's kernel trace, where the learn chain falls behind: 224 us per policy launch)
@@ -274,7 +288,7 @@ __device__ __forceinline__ void await_image(int *cursor, const long long *step_d
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
                 __builtin_amdgcn_s_sleep(127);
                 if (wall_clock64() - t0 > TT_IMAGE_WAIT_TICKS) {      // never hang: leave a mark the host checks, and go on
-                    __hip_atomic_store(cursor + CUR_GAVE_UP, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mark_gave_up(cursor, want);
                     break;
                 }
             }
@@ -300,7 +314,7 @@ __device__ __forceinline__ void await_progress(int *progress, const long long *k
             while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
                 __builtin_amdgcn_s_sleep(32);
                 if (wall_clock64() - t0 > TT_IMAGE_WAIT_TICKS) {
-                    __hip_atomic_store(progress - CUR_PROGRESS + CUR_GAVE_UP, want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mark_gave_up(progress - CUR_PROGRESS, want + 1);
                     break;
                 }
             }

@@ -55,7 +55,7 @@ class Truck_trailer_Env_2:
         self.position_threshold = p.position_threshold
         self.orientation_threshold = p.orientation_threshold
         self.steering_angle = 0
-        self.episode_steps = 0
+        object.__setattr__(self, "episode_steps", 0)
         self.reward_state = None
         self.jackknife = self.out_of_map = self.max_steps_reached = self.goal_reached = self.goal_passed = False
         self.excessive_backward = False
@@ -77,6 +77,8 @@ class Truck_trailer_Env_2:
             self._dirty.add("attrs")
         elif name == "max_episode_steps":
             self._dirty.add("max_steps")
+        elif name == "episode_steps":     # a caller's write (episode_replay_collectorv2.py:269); step() / reset() bypass this
+            self._dirty.add("steps")
         object.__setattr__(self, name, value)
 
     @property
@@ -99,6 +101,8 @@ class Truck_trailer_Env_2:
                                 goal=[[self.goalx, self.goaly, self.goalyaw]], L2=[self.L2], idx=list(idx))
         if "max_steps" in d:
             self._vec.set_max_steps([int(self.max_episode_steps)], idx=list(idx))
+        if "steps" in d:
+            self._vec.set_steps([int(self.episode_steps)], idx=list(idx))
         d.clear()
         if self._state_pending:
             self._vec.set_state(self._state[None, :], idx=list(idx))
@@ -145,7 +149,7 @@ class Truck_trailer_Env_2:
         self._dirty.clear()
         self._state_pending = False
         self._state_stale = True
-        self.episode_steps = 0
+        object.__setattr__(self, "episode_steps", 0)
         self.reward_state = None
         return obs[0].cpu().numpy(), {}
 
@@ -160,7 +164,7 @@ class Truck_trailer_Env_2:
         comp = inf["comp"][:, 0].cpu().numpy()
         flags = int(inf["flags"][0].item())
         viol = int(inf["violation"][0].item())
-        self.episode_steps += 1
+        object.__setattr__(self, "episode_steps", self.episode_steps + 1)      # the kernel counted the step
         self._state_stale = True
         self.jackknife = bool(flags & L.F_JACKKNIFE)
         self.out_of_map = bool(flags & L.F_OUT_OF_MAP)

@@ -76,7 +76,19 @@ class TrajectoryRing:
         # [4..7] / [8..11]: the cursors {t, t+1, t-1, t > 0} of even / odd steps, [0..3]: the running step's (include/ttenv.h)
         # ring cursors [0..11] + the image hand-over words [12..15] (include/ttenv.h: TT_CURSOR_INTS)
         # [16]: the step chain's progress (k + 1 once the policy launch of step k has begun): what a pipelined learn() waits for
+        # [18..19]: address of the host word below (TT_CURSOR_GAVE_UP_MIRROR)
         self.cursor_dev = torch.zeros(32, dtype=torch.int32, device=device)
+        # a launch that gives up waiting for the other chain marks cursor[15] AND this word of pinned (device-visible) host
+        # memory: the host sees a give-up by reading its own memory, with no copy or synchronize in the loop
+        self.gave_up_host = None
+        if torch.device(device).type == "cuda":
+            self.gave_up_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._gave_up_np = self.gave_up_host.numpy()
+            self._write_mirror_address()
+
+    def _write_mirror_address(self):
+        if self.gave_up_host is not None:
+            self.cursor_dev[18:20] = torch.tensor([self.gave_up_host.data_ptr()], dtype=torch.int64).view(torch.int32).to(self.device)
 
     def attach(self, env):
         """Let the env's step kernel advance k_dev (tt_env_set_step_counter): one launch less per vector step.  From
@@ -164,12 +176,34 @@ class TrajectoryRing:
         self.k_dev.fill_(self.k)
         self.cursor_dev.zero_()             # image epochs are step numbers: a counter set back must not find newer ones
         self.cursor_dev[16] = self.k        # ... and the step chain is where the counters say (TT_CURSOR_PROGRESS)
+        self._write_mirror_address()
+        if self.gave_up_host is not None:
+            self._gave_up_np[0] = 0
 
     def policy_gave_up(self):
         """Step number + 1 at which a launch stopped waiting for the other chain -- a policy launch for its image, or learn()'s first
         launch for the step chain's progress (include/ttenv.h: TT_CURSOR_GAVE_UP, TT_CURSOR_PROGRESS) --, 0 = never.
         Synchronises."""
-        return int(self.cursor_dev[15].item())
+        return int(self.cursor_dev[15].item()) or self.gave_up_seen()
+
+    def gave_up_seen(self):
+        """The same mark as the host sees it WITHOUT touching the GPU (the launch that gives up also sets a word of pinned host
+        memory: TT_CURSOR_GAVE_UP_MIRROR): what a loop looks at between graph replays.  A mark not yet visible here is seen
+        by the next look; policy_gave_up() is the exact, synchronising form."""
+        return int(self._gave_up_np[0]) if self.gave_up_host is not None else 0
+
+    def mark_gave_up_for_test(self, step):
+        """What a launch of vector step `step` that gives up leaves behind (device word and host mirror): tests of the fallback."""
+        self.cursor_dev[15] = int(step) + 1
+        torch.cuda.current_stream(self.device).synchronize()
+        if self.gave_up_host is not None:
+            self._gave_up_np[0] = int(step) + 1
+
+    def clear_gave_up(self):
+        self.cursor_dev[15] = 0
+        if self.gave_up_host is not None:
+            torch.cuda.current_stream(self.device).synchronize()
+            self._gave_up_np[0] = 0
 
     def view(self):
         from ddpg_trucktrailer_amd import _lib as L

@@ -142,6 +142,10 @@ class DDPGRollout:
         self.graphG = None              # graph_steps vector steps (one rank)
         self.dp_graphs = None
         self._graph_epoch = None        # env.graph_epoch the captures were made under
+        # hand-overs through device memory (policy image, step progress) are bounded waits: a launch that gives up goes on with
+        # stale inputs.  The loop notices (_check_handover), falls back to graph edges once, and raises the second time
+        self.handover_gave_up = []      # steps (+1) at which a launch gave up, in the order they were noticed
+        self._edge_forced = False
 
     # -------------------------------------------------------------- acting
     @torch.no_grad()
@@ -271,11 +275,46 @@ class DDPGRollout:
         (TT_POLICY_EDGE=graph) and under rocprofv3: a tool that intercepts every dispatch keeps the learn chain ~45 us per
         launch behind, the policy launch then spends its life waiting (189 us per launch in a kernel trace) and the trace says
         nothing about the loop; with --pmc (kernels serialised) a waiting launch would only leave by its time limit."""
-        if os.environ.get("TT_POLICY_EDGE", "flag") == "graph" or self.updates_per_step > 1 or self.dp:
+        if os.environ.get("TT_POLICY_EDGE", "flag") == "graph" or self.updates_per_step > 1 or self.dp or self._edge_forced:
+            return "graph"
+        # a policy workgroup takes a whole CU (155 KB of LDS): a grid that is not capped BELOW the number of CUs fills the chip,
+        # and a policy launch that spins there for its image keeps the learn chain -- which makes the image -- off the GPU
+        if self.policy_workgroups <= 0 or self.policy_workgroups >= self._cu_count():
             return "graph"
         if os.environ.get("TT_POLICY_EDGE") != "flag" and any(k.startswith("ROCPROF") or k == "ROCP_TOOL_LIBRARIES" for k in os.environ):
             return "graph"
         return "flag"
+
+    def _cu_count(self):
+        if not hasattr(self, "_cus"):
+            self._cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count) if self.device.type == "cuda" else 0
+        return self._cus
+
+    def _check_handover(self, exact=False):
+        """Has a launch given up waiting for the other chain of its step (include/ttenv.h: TT_CURSOR_GAVE_UP)?  exact=False reads
+        the host-visible mirror of the word -- no GPU call, done after every graph replay --, exact=True synchronises and reads
+        the device word (state_dict, prepare, the end of a checkpoint).  The first time: warn, drop the graphs and capture them
+        again with graph edges between the chains (what bench.py does in its setup: ~4 us per step slower, never waits).  A
+        second time -- with edges no launch ever has to wait -- is an error."""
+        ring = self.ring
+        if not self.ring_mode or ring.gave_up_host is None:
+            return 0
+        mark = ring.policy_gave_up() if exact else ring.gave_up_seen()
+        if not mark:
+            return 0
+        import warnings
+        self.handover_gave_up.append(int(mark))
+        torch.cuda.synchronize(self.device)
+        ring.clear_gave_up()
+        if self.policy_edge() == "graph":
+            raise RuntimeError(f"a launch of vector step {mark - 1} gave up waiting for the other chain of its step although the "
+                               "chains are ordered by graph edges: the loop's state is not trustworthy (DESIGN.md section 11)")
+        warnings.warn(f"a launch of vector step {mark - 1} gave up waiting (0.25 s) for the other chain of its step -- the policy for its "
+                      "image, or learn() for the env step -- and went on with stale inputs; capturing the steps again with graph edges "
+                      "between the chains (as TT_POLICY_EDGE=graph does)")
+        self._edge_forced = True
+        self.invalidate_graphs()
+        return int(mark)
 
     def policy_launch(self):
         """The policy launch of the running step alone (ring mode; after _open_step): bench.py times it."""
@@ -389,7 +428,11 @@ class DDPGRollout:
         # that time (learn() 5 us per update slower beside it), so there the launch is held back by the edge.
         # Data-parallel ranks keep the edge as well: that path has never run on more than one GPU, and a collective that takes
         # long inside the learn chain must never meet a policy launch with a time limit.
-        edge = self.policy_edge() == "graph"
+        # ... and so do the short graphs (the 4-step and the single-step one): with the device-memory hand-over a graph keeps an
+        # edge between its chains only every _LEARN_EDGE_EVERY-th step from step 2 on, so a graph that short would hold two chains
+        # with NO edge at all -- the shape that starts ~0.2 ms late into an idle GPU (below) and that lets the policy wait for
+        # learn packets which are not queued yet.  They serve the remainders of a run(k), not its bulk.
+        edge = self.policy_edge() == "graph" or steps <= _LEARN_EDGE_EVERY
         for t in range(steps):
             with torch.cuda.stream(side):
                 # (without the hand-over through device memory: every step; with it: every _LEARN_EDGE_EVERY-th step, see below)
@@ -493,6 +536,7 @@ class DDPGRollout:
         steady-state steps only.  Advances the loop by 4 vector steps."""
         while self.ring.k < 4:
             self.step()
+        self._check_handover(exact=True)
         if self.graph_steps and not self._graphs_current():
             self._try_capture()
 
@@ -512,6 +556,7 @@ class DDPGRollout:
         if self.learner is not None:
             self.learner.refresh_images()      # fc2 written by anyone but the learner's own launches since the last look?
         while k > 0:
+            self._check_handover()             # (a host-memory read; a give-up drops the graphs: captured again just below)
             G = self.graph_steps
             if G and ring.k >= 4 and (self._graphs_current() or self._try_capture()):
                 if self.dp and not self.dp_single_graph:
@@ -532,6 +577,7 @@ class DDPGRollout:
             else:
                 self.step()
                 k -= 1
+        self._check_handover()
 
     # -------------------------------------------------------------- checkpoint / resume of the whole loop
     def state_dict(self):
@@ -540,8 +586,10 @@ class DDPGRollout:
         its counters, the OU state.  The RNG streams of the loop are counter-based (Philox keyed by seed and the
         counters saved here), so there is no generator state to save."""
         torch.cuda.synchronize(self.device) if self.device.type == "cuda" else None
+        self._check_handover(exact=True)
         ag = self.agent
         sd = {"format": 2, "seed": int(self.seed), "vector_steps": int(self.vector_steps),
+              "handover_gave_up": [int(x) for x in self.handover_gave_up],
               "batch_size": int(self.batch_size), "updates_per_step": self.updates_per_step,
               "nets": {n: {k: v.detach().cpu().clone() for k, v in getattr(ag, n).state_dict().items()}
                        for n in ("actor", "critic", "target_actor", "target_critic")},
@@ -574,5 +622,6 @@ class DDPGRollout:
         if int(sd["seed"]) != int(self.seed):
             self.invalidate_graphs()                                  # the Philox keys are kernel arguments
         self.seed = int(sd["seed"])
+        self.handover_gave_up = [int(x) for x in sd.get("handover_gave_up", [])]
         self.vector_steps = int(sd["vector_steps"])
         self.updates_per_step = int(sd.get("updates_per_step", self.updates_per_step))

@@ -149,6 +149,16 @@ class TruckTrailerVecEnv:
         idx = self._as(idx, torch.int32, (k,)) if idx is not None else None
         self._check(self.lib.tt_env_set_max_steps(self._h, _ptr(idx), k, _ptr(m), self._stream()))
 
+    def set_steps(self, steps, idx=None):
+        """`env.episode_steps = ...` for envs idx (default 0..k-1): the step counter alone, the reward carry stays
+        (include/ttenv.h: tt_env_set_steps)."""
+        m = self._as(steps, torch.int32).reshape(-1)
+        k = m.shape[0]
+        if k and (int(m.min()) < 0 or int(m.max()) > L.MAX_EPISODE_STEPS):
+            raise ValueError(f"episode_steps must lie in [0, {L.MAX_EPISODE_STEPS}] (12-bit packed counters)")
+        idx = self._as(idx, torch.int32, (k,)) if idx is not None else None
+        self._check(self.lib.tt_env_set_steps(self._h, _ptr(idx), k, _ptr(m), self._stream()))
+
     # ------------------------------------------------------------------ read-back
     @property
     def state(self):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TT_VERSION 2
+#define TT_VERSION 3
 #define TT_OBS_DIM 23 /* simv2.py:76 */
 #define TT_MAX_EPISODE_STEPS 4095 /* steps and max_episode_steps are 12-bit packed counters; larger values are TT_EINVAL */
 
@@ -134,6 +134,12 @@ int tt_env_get_state(tt_env *env, double *state_out, tt_stream_t stream);
  * (a setter, not a hot call; not capturable). */
 int tt_env_set_max_steps(tt_env *env, const int32_t *idx, int k, const int32_t *max_steps, tt_stream_t stream);
 
+/* `env.episode_steps = ...` (simv2.py:94, 523-530; written by a caller at DDPG/episode_replay_collectorv2.py:269) for envs
+ * idx[j]: the step counter that the exploration tiers, the max-step penalty and `max_steps_reached` read.  Like the
+ * reference's attribute write it leaves the reward carry alone (reward_state: previous distance, backward-movement count,
+ * stage latches -- only reset / tt_env_set_pose clear it).  Range-checked and synchronising like tt_env_set_max_steps. */
+int tt_env_set_steps(tt_env *env, const int32_t *idx, int k, const int32_t *steps, tt_stream_t stream);
+
 /* Episode bookkeeping read-back; any pointer may be NULL.  steps/max_steps [N] i32;
  * start, goal [3,N] f64 (startx.., goalx..: trainv2.py:503-508); L2 [N] f64. */
 int tt_env_get_episode(tt_env *env, int32_t *steps, int32_t *max_steps, double *start, double *goal, double *L2,
@@ -182,6 +188,10 @@ typedef struct tt_ring_cursor {
  * pack launch of step k + 2, which overwrites the same image, must still be ordered behind the policy launch of step k. */
 #define TT_CURSOR_INTS 32
 #define TT_CURSOR_GAVE_UP 15
+/* cursor[18..19] (optional, 0 = none): the 64-bit address of ONE int of device-visible host memory (hipHostMalloc; a torch
+ * pinned tensor) that a launch which gives up sets as well (system scope), so that the host sees a give-up by reading its own
+ * memory, without a copy or a synchronize.  The caller writes the address whenever it zeroes the cursor buffer. */
+#define TT_CURSOR_GAVE_UP_MIRROR 18
 /* Step-chain progress (cursor[16]): tt_actor_act_ring of step k begins by storing k + 1 there (device scope).  A launch starts
  * only when everything in front of it on its stream is complete and written back, so cursor[16] >= k + 1 says: the env step of
  * step k - 1 -- and every launch before it -- is over and visible.  tt_mlp_forward_multi_sampled can wait for that word instead of

@@ -50,7 +50,7 @@ def test_errors_are_codes_not_exceptions(lib):
     assert b"n_envs" in dll.tt_last_error(None)
     assert dll.tt_env_step(None, None, None, None, None, None, 0, None) == lib.TT_EINVAL
     assert dll.tt_env_destroy(None) == lib.TT_OK
-    assert dll.tt_version() == 2
+    assert dll.tt_version() == 3
 
 
 def test_product_does_not_import_oracle():

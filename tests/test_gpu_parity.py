@@ -74,6 +74,67 @@ def test_fixture_trajectory_through_gym_facade(torch_mod, t):
     assert [bool(i["success"]) for i in r["info"]] == t["success"].tolist()
 
 
+def _f7():
+    from conftest import load_group
+    return [pytest.param(t, id=f"f7-{n}") for n, t in load_group("f7_episode_steps.npz").items()]
+
+
+@pytest.mark.parametrize("t", _f7())
+def test_episode_steps_written_through_the_facade(torch_mod, t):
+    """Fixture F7 (the reference with `env.episode_steps = k` written between steps): the facade's attribute write goes through
+    tt_env_set_steps and moves the device step counter alone -- exploration tiers, max-step penalty and `max_steps_reached`
+    follow it, the reward carry (movement budget, progress window, first steering) does not.  The `no_reset` case is the caller
+    pattern of DDPG/episode_replay_collectorv2.py:258-269 on an env object that was never reset."""
+    from ddpg_trucktrailer_amd.env import Truck_trailer_Env_2
+    writes = {int(i): int(v) for i, v in t["writes"]}
+    env = Truck_trailer_Env_2()
+    if not bool(t["no_reset"]):
+        env.reset(seed=0)
+    env.state = t["state0"].astype(np.float32) if bool(t["no_reset"]) else t["state0"]
+    env.startx, env.starty, env.startyaw = (float(x) for x in t["start"])
+    env.goalx, env.goaly, env.goalyaw = (float(x) for x in t["goal"])
+    env.max_episode_steps = env.compute_max_steps()
+    if int(t["max_episode_steps"]) != env.max_episode_steps:
+        env.max_episode_steps = int(t["max_episode_steps"])
+    if bool(t["no_reset"]):
+        env.episode_steps = 0
+    assert np.abs(env.compute_observation(env.state, 0.0) - t["obs0"]).max() <= TOL
+    steps = 0
+    for k, a in enumerate(t["actions"]):
+        if k in writes:
+            env.episode_steps = steps = writes[k]
+        o, r, d, info = env.step(np.array([a], np.float32))
+        steps += 1
+        assert env.episode_steps == steps and int(env._vec.episode()["steps"][0].item()) == steps, k
+        assert np.abs(env.state - t["states"][k]).max() <= TOL and np.abs(o - t["obs"][k]).max() <= TOL, k
+        assert abs(r - t["reward"][k]) <= TOL and d == bool(t["done"][k]) and info["violation_type"] == VIOL[t["violation"][k]], k
+        assert [env.jackknife, env.out_of_map, env.max_steps_reached, env.goal_reached, env.goal_passed,
+                env.excessive_backward] == t["flags"][k].tolist(), k
+        assert abs(info["exploration_bonus"] - t["info"][k, 7]) <= TOL and abs(info["safety_penalty"] - t["info"][k, 6]) <= TOL, k
+        assert abs(info["backward_movement_info"]["movement_budget"] - t["info"][k, 12]) <= TOL, k
+        assert abs(info["backward_penalty"] - t["info"][k, 9]) <= TOL and abs(info["smoothness_penalty"] - t["info"][k, 10]) <= TOL, k
+    with pytest.raises(ValueError):
+        env.episode_steps = 5000
+        env.step(np.array([0.0], np.float32))
+    env.close()
+
+
+def test_set_steps_is_range_checked_at_the_c_abi(torch_mod):
+    import ctypes as C
+    torch = torch_mod
+    from ddpg_trucktrailer_amd import _lib as L
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    env = TruckTrailerVecEnv(8)
+    env.reset(seed=3)
+    bad = torch.tensor([1, 4096], dtype=torch.int32, device="cuda")
+    rc = env.lib.tt_env_set_steps(env._h, None, 2, C.c_void_p(bad.data_ptr()), None)
+    assert rc == L.TT_EINVAL and b"4096" in env.lib.tt_last_error(env._h)
+    assert (env.episode()["steps"].cpu().numpy() == 0).all()                 # nothing was written
+    env.set_steps([7, 4095], idx=[5, 2])
+    assert env.episode()["steps"].cpu().numpy().tolist() == [0, 0, 4095, 0, 0, 7, 0, 0]
+    env.close()
+
+
 def test_golden_episode_against_the_authors_recording(torch_mod):
     """F1 against what the reference's author recorded (not only our replay of it)."""
     from conftest import load_group

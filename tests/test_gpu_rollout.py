@@ -446,6 +446,112 @@ def test_image_handover_through_device_memory_over_many_steps(gpu_device):
     assert torch.isfinite(outs[0][0]).all()
 
 
+def test_run_notices_a_give_up_and_falls_back_to_graph_edges(gpu_device, monkeypatch, tmp_path):
+    """A launch that gives up waiting for the other chain of its step (0.25 s) goes on with stale inputs and leaves a mark
+    (include/ttenv.h: TT_CURSOR_GAVE_UP + its host-visible mirror).  DDPGRollout.run() -- not only bench.py -- must notice it
+    without a synchronize in the loop: warn, capture the steps again with graph edges between the chains and go on; results
+    then equal a loop that had graph edges from the start, bit for bit (the mark is set artificially: no launch stalled, so no
+    step is actually stale); a second mark raises; a checkpoint of such a loop is refused.  Reference semantics at stake: the
+    policy acts with the weights learn() of step t-1 left (DDPG/trainv2.py:511-531)."""
+    import warnings
+    import torch
+    from ddpg_trucktrailer_amd import checkpoint
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    monkeypatch.delenv("TT_POLICY_EDGE", raising=False)
+
+    def make(**kw):
+        env = TruckTrailerVecEnv(4096)
+        env.reset(seed=5)
+        return DDPGRollout(env, batch_size=256, replay_slots=16, seed=5, graph_steps=20, **kw)
+    a = make()
+    if a.policy_edge() != "flag":
+        pytest.skip("the loop already uses graph edges here (a tool is attached)")
+    a.run(4 + 20 + 4 + 1)
+    torch.cuda.synchronize()
+    assert a.handover_gave_up == [] and a.ring.gave_up_seen() == 0
+    a.ring.mark_gave_up_for_test(a.ring.k - 1)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        a.run(20 + 4 + 1)                                  # notices at its first look, re-captures, goes on
+    assert any("gave up waiting" in str(w.message) for w in seen)
+    assert a.handover_gave_up == [29] and a.policy_edge() == "graph" and a.graphG is not None
+    assert a.ring.policy_gave_up() == 0                    # both words cleared
+    monkeypatch.setenv("TT_POLICY_EDGE", "graph")
+    b = make()
+    b.run(4 + 20 + 4 + 1 + 20 + 4 + 1)
+    torch.cuda.synchronize()
+    assert a.ring.k == b.ring.k == 54
+    assert torch.equal(_loop_flat(a), _loop_flat(b)) and torch.equal(a.env.state, b.env.state)
+    for name in ("obs", "act", "rew", "done"):
+        assert torch.equal(getattr(a.ring, name), getattr(b.ring, name)), name
+    # a checkpoint of a loop with a give-up in its history is refused; force=True writes it, history included
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        checkpoint.save_loop_checkpoint(str(tmp_path / "no.pt"), a)
+    assert not (tmp_path / "no.pt").exists()
+    path = checkpoint.save_loop_checkpoint(str(tmp_path / "forced.pt"), a, force=True)
+    assert torch.load(path, weights_only=True)["loop"]["handover_gave_up"] == [29]
+    checkpoint.save_loop_checkpoint(str(tmp_path / "ok.pt"), b)
+    # state_dict() looks at the DEVICE word (exact): a mark the mirror never got is still found
+    b.ring.cursor_dev[15] = 7
+    with pytest.raises(RuntimeError, match="ordered by graph edges"):
+        b.state_dict()
+    monkeypatch.delenv("TT_POLICY_EDGE")
+    # ... and with edges already in place a second give-up is an error in run() as well
+    a.ring.mark_gave_up_for_test(a.ring.k - 1)
+    with pytest.raises(RuntimeError, match="ordered by graph edges"):
+        a.run(1)
+    a.env.close(); b.env.close()
+
+
+def test_a_launch_that_really_gives_up_reaches_the_host(gpu_device, monkeypatch):
+    """The device side of the above: a policy launch whose image epoch never arrives leaves after 0.25 s and sets the give-up
+    word AND its mirror in pinned host memory, which the host reads without any GPU call."""
+    import time
+    import torch
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    monkeypatch.delenv("TT_POLICY_EDGE", raising=False)
+    env = TruckTrailerVecEnv(1024)
+    env.reset(seed=2)
+    loop = DDPGRollout(env, batch_size=256, replay_slots=16, seed=2, graph_steps=4)
+    loop.prepare()
+    torch.cuda.synchronize()
+    k = loop.ring.k
+    assert loop.ring.gave_up_seen() == 0
+    loop.ring.cursor_dev[12:14] = 0                        # the epochs of both parities: "no image has ever been published"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop.policy_launch()                                   # waits for epoch k + 1, bounded
+    torch.cuda.synchronize()
+    waited = time.perf_counter() - t0
+    assert 0.2 < waited < 5.0, waited
+    assert loop.ring.gave_up_seen() == k + 1               # host memory, written by the kernel (system scope)
+    assert int(loop.ring.cursor_dev[15].item()) == k + 1
+    loop.ring.clear_gave_up()
+    assert loop.ring.policy_gave_up() == 0
+    env.close()
+
+
+def test_policy_edge_follows_the_grid_cap(gpu_device, monkeypatch):
+    """A policy grid that is not capped below the CU count fills the chip (one workgroup per CU: 155 KB of LDS), and a launch
+    spinning there for its image would keep the learn chain that makes the image off the GPU: such loops use graph edges."""
+    import torch
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    monkeypatch.delenv("TT_POLICY_EDGE", raising=False)
+    monkeypatch.delenv("TT_POLICY_WG", raising=False)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    env = TruckTrailerVecEnv(1024)
+    env.reset(seed=2)
+    tool = any(k.startswith("ROCPROF") or k == "ROCP_TOOL_LIBRARIES" for k in __import__("os").environ)
+    for wg, want in ((192, "graph" if tool or 192 >= cus else "flag"), (0, "graph"), (cus, "graph"), (cus + 64, "graph")):
+        loop = DDPGRollout(env, batch_size=256, replay_slots=16, seed=2, graph_steps=4, policy_workgroups=wg)
+        assert loop.policy_edge() == want, (wg, cus)
+    assert DDPGRollout(env, batch_size=256, replay_slots=16, seed=2, graph_steps=4, updates_per_step=2).policy_edge() == "graph"
+    env.close()
+
+
 @pytest.mark.parametrize("pipeline", [True, False])
 def test_pipelined_and_serial_orders(gpu_device, pipeline):
     """Both orders of a vector step: graphs == eager bit for bit, exactly one learn() per step from the third step on,

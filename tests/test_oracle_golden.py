@@ -83,6 +83,46 @@ def test_c_oracle_within_tolerance(t):
     assert np.abs(r["info"] - fix).max() <= TOL
 
 
+def _f7():
+    return [pytest.param(t, id=f"f7-{n}") for n, t in load_group("f7_episode_steps.npz").items()]
+
+
+@pytest.mark.parametrize("t", _f7())
+def test_episode_steps_written_by_the_caller(t):
+    """Fixture F7: `env.episode_steps = k` between steps of the reference (episode_replay_collectorv2.py:258-269) moves the step
+    counter alone; the reward carry keeps its own step count.  Twin (bit-faithful) and C oracle, free-running."""
+    writes = {int(i): int(v) for i, v in t["writes"]}
+    env = Simv2Twin()
+    env.set_pose(t["start"], goal=tuple(t["goal"]), L2=float(t["L2"]), state=t["state0"] if needs_raw_state(t) else None,
+                 max_steps=int(t["max_episode_steps"]))
+    o = c_oracle.COracle(1)
+    o.place(t["start"], goal=t["goal"], L2=float(t["L2"]))
+    if needs_raw_state(t):
+        o.set_state(0, t["state0"])
+    o.set_max_steps(0, int(t["max_episode_steps"]))
+    for k, a in enumerate(t["actions"]):
+        if k in writes:
+            env.episode_steps = writes[k]
+            o.envs[0].steps = writes[k]
+        ob, r, d, info = env.step(np.array([a], np.float32))
+        assert np.abs(env.state - t["states"][k]).max() <= 1e-12 and np.abs(ob - t["obs"][k]).max() <= 1e-7, k
+        assert abs(r - t["reward"][k]) <= 1e-9 and d == t["done"][k] and info["violation"] == t["violation"][k], k
+        assert [env.flags[f] for f in FLAG_KEYS] == t["flags"][k].tolist(), k
+        assert abs(info["movement_budget"] - t["info"][k, 12]) <= 1e-12 and abs(info["exploration_bonus"] - t["info"][k, 7]) <= 1e-12
+        cob, cr, cd, cinfo = o.step([a])
+        assert np.abs(o.state()[0] - t["states"][k]).max() <= TOL and np.abs(cob[0] - t["obs"][k]).max() <= TOL, k
+        assert abs(cr[0] - t["reward"][k]) <= TOL and bool(cd[0]) == bool(t["done"][k]) and o.violation()[0] == t["violation"][k], k
+        assert [(o.flags()[0] >> b) & 1 for b in range(6)] == t["flags"][k].astype(int).tolist(), k
+        assert np.abs(cinfo[0] - t["info"][k, [0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12]]).max() <= TOL, k
+    # the fixture really separates the two counters: somewhere the budget differs from what the step counter would give
+    if len(writes):
+        steps, sep = 0, False
+        for k in range(len(t["actions"])):
+            steps = writes.get(k, steps) + 1
+            sep |= abs(5.0 * min(1.0, steps / 50) - t["info"][k, 12]) > 1e-9
+        assert sep
+
+
 def test_golden_episode_recording_is_the_authority():
     """The fixture's replayed states/rewards agree with what the reference's author recorded."""
     t = load_group("f1_golden_episode.npz")["golden"]

@@ -96,8 +96,6 @@ def test_f6_trajectories_on_the_hip_kernel(gpu_device, name):
     from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
     z = _f6()
     g = lambda k: z[f"traj/{name}/{k}"]
-    if int(g("steps_before")):
-        pytest.skip("the C ABI has no setter for the step counter; the free-running 300-step trajectory covers the cap")
     n = 64                                       # one wave: every lane runs the same episode
     env = TruckTrailerVecEnv(n, variant=1)
     p = env.params
@@ -106,6 +104,9 @@ def test_f6_trajectories_on_the_hip_kernel(gpu_device, name):
     obs0 = env.set_pose(torch.tensor(np.broadcast_to(g("start"), (n, 3)).copy(), device="cuda"))
     assert np.abs(obs0.cpu().numpy() - g("obs0")).max() <= 1e-6
     assert np.abs(env.state.cpu().numpy() - g("state0")).max() == 0.0
+    if int(g("steps_before")):                   # the generator wrote env.episode_steps on the reference: tt_env_set_steps
+        env.set_steps([int(g("steps_before"))] * n)
+        assert (env.episode()["steps"].cpu().numpy() == int(g("steps_before"))).all()
     bits = (L.F_JACKKNIFE, L.F_OUT_OF_MAP, L.F_MAX_STEPS, L.F_GOAL_REACHED)
     for t, a in enumerate(g("actions")):
         obs, rew, done, info = env.step(torch.full((n,), float(a), dtype=torch.float32, device="cuda"), auto_reset=False, info=True)
