@@ -57,11 +57,14 @@ def parse():
     ap.add_argument("--serial", action="store_true", help="ddpg workload: the reference's strict order (policy, env step, then "
                     "learn() on a window that includes the new step) instead of the pipelined one")
     ap.add_argument("--graph-steps", type=int, default=50, help="env workload: vector steps per captured hipGraph")
-    ap.add_argument("--dp-mode", choices=("auto", "graph", "segments"), default="auto",
+    ap.add_argument("--dp-mode", choices=("auto", "graph", "segments", "p2p"), default="auto",
                     help="N > 1, ddpg workload: launch structure of a data-parallel vector step.  graph: one hipGraph per step "
                     "with the two RCCL all-reduces as its nodes; segments: three hipGraph segments with eager all-reduces "
                     "between them; auto: graph where every rank's probe (dp_probe) saw a captured all-reduce replay "
-                    "correctly, else segments.  The structure that ran is in config.launch / config.dp_mode")
+                    "correctly, else segments; p2p: NO collective on learn()'s chain -- every rank's Adam launch reads the peers' "
+                    "gradient buffers itself (IPC-opened device memory, flag barrier; include/ttenv.h: tt_p2p_*), one hipGraph per "
+                    "step of plain kernel launches (also with --gpus 1: the same launches against the rank's own block).  The "
+                    "structure that ran is in config.launch / config.dp_mode")
     ap.add_argument("--settle-ms", type=float, default=None,
                     help="setup ends with this many milliseconds of untimed vector steps (default: 100 for the ddpg workload, env "
                          "TT_BENCH_SETTLE_MS; 0: none): after the idle of graph capture the GPU needs ~30 ms under load to reach its "
@@ -333,7 +336,10 @@ def main():
 
     nccl = os.environ.get("TT_DIST_BACKEND", "nccl") == "nccl"
     dp_vote, dp_asked = False, "n/a"
-    if world > 1 and args.workload == "ddpg" and nccl:
+    p2p = args.dp_mode == "p2p" and args.workload == "ddpg"
+    if p2p:
+        dp_vote, dp_asked = True, "--dp-mode p2p"
+    elif world > 1 and args.workload == "ddpg" and nccl:
         # one hipGraph per data-parallel step if this node replays a captured RCCL all-reduce correctly: asked in
         # throw-away child processes before this rank touches its GPU (ddpg-trucktrailer_amd/dp_probe.py).  The answer
         # here is this rank's VOTE; the ranks agree on one structure below, once the process group exists.
@@ -417,7 +423,8 @@ def main():
         loop = DDPGRollout(env, batch_size=args.batch, replay_slots=args.replay_slots, seed=27 + rank,
                            world_size=world, use_graph=not args.no_graph, fused_learn=not args.torch_learn,
                            graph_steps=args.step_graph, updates_per_step=args.updates_per_step,
-                           pipeline=False if args.serial else None, graph_collectives=dp_graph)
+                           pipeline=False if args.serial else None, graph_collectives=dp_graph,
+                           dp_exchange="p2p" if p2p else None, data_parallel=True if p2p else None)
         wd.enter("prepare (eager steps + graph capture)")
         loop.prepare()       # one-off work (4 untimed vector steps + graph capture) before warm-up and the timed region
         wd.enter("first graph launches")
@@ -429,7 +436,9 @@ def main():
                     f"batch {args.batch}, OU noise, replay ring {args.replay_slots}xN) (BASELINE config {5 if variant else 3})")
         if loop.graph_steps:
             launch = (f"every vector step a hipGraph replay: graphs of {loop.graph_steps}, 4 and 1 whole steps "
-                      f"serve every ring position (device cursor)" + (" -- the two RCCL gradient all-reduces of a step are nodes of its graph"
+                      f"serve every ring position (device cursor)" + ((" -- no collective: each rank's two Adam launches read the peers' gradient "
+                                                                "buffers themselves (IPC-opened device memory, flag barrier)" if p2p else
+                                                                " -- the two RCCL gradient all-reduces of a step are nodes of its graph")
                                                                if loop.dp else "") if not (loop.dp and not loop.dp_single_graph) else
                       "three hipGraph segments per step with the two RCCL gradient all-reduces between them")
         else:
@@ -441,7 +450,7 @@ def main():
                  "replay_capacity": args.replay_slots * n, "launch": launch, "order": order,
                  "dp_mode": (None if not loop.dp else
                              {"asked": args.dp_mode, "decided_by": dp_asked, "this_rank_vote": bool(dp_vote),
-                              "agreed_by_all_ranks": "graph" if loop.dp_single_graph else "segments"}),
+                              "agreed_by_all_ranks": "p2p" if p2p else ("graph" if loop.dp_single_graph else "segments")}),
                  "env_steps_per_update": n / args.updates_per_step, "setup_vector_steps": loop.vector_steps,
                  "note": ("throughput of the configuration BASELINE.json names; how the same loop trains at this and at other "
                           "update ratios (--updates-per-step): profiles/r03_training_behaviour.md")}

@@ -151,6 +151,17 @@ _SIGNATURES = {
                                           C.c_float, C.c_float, C.POINTER(TTFc2Images), _P, _P]),
     "tt_adam_soft_update": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                       C.c_float, C.c_float, C.POINTER(TTFc2Images), _P, _P]),
+    "tt_p2p_create": (C.c_int, [_I, _I, _I, _I, _P, C.POINTER(_P)]),
+    "tt_p2p_destroy": (C.c_int, [_P]),
+    "tt_p2p_export": (C.c_int, [_P, _P]),
+    "tt_p2p_attach": (C.c_int, [_P, _I, _P]),
+    "tt_p2p_grad": (_P, [_P, _I]),
+    "tt_p2p_reset": (C.c_int, [_P, _P]),
+    "tt_p2p_set_timeout": (C.c_int, [_P, C.c_double]),
+    "tt_p2p_gave_up": (C.c_int, [_P]),
+    "tt_p2p_last_error": (C.c_char_p, [_P]),
+    "tt_adam_soft_update_p2p": (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
+                                          C.c_float, C.c_float, C.POINTER(TTFc2Images), _P, _P]),
     "tt_mlp_fc2_image_bytes": (C.c_uint64, []),
     "tt_mlp_fc2_image_pack": (C.c_int, [C.POINTER(TTMlpWeights), _P]),
     "tt_td_target": (C.c_int, [_I, _P, _P, _P, C.c_float, _P, _P, _P]),
@@ -185,6 +196,15 @@ def check(rc, handle=None):
     if rc != TT_OK:
         msg = load().tt_last_error(handle)
         raise TTError(f"libttenv error {rc}: {msg.decode() if msg else '?'}")
+
+
+def check_p2p(rc, handle=None):
+    if rc != TT_OK:
+        msg = load().tt_p2p_last_error(handle)
+        raise TTError(f"libttenv p2p error {rc}: {msg.decode() if msg else '?'}")
+
+
+P2P_HANDLE_BYTES, P2P_MAX_RANKS = 64, 8
 
 
 def default_params(variant=0):

@@ -22,6 +22,7 @@
 #include "ttenv.h"
 #include "ttnet_common.h"      // the replay draw (ring_sample_index): k_fwd_multi can make it itself
 #include "ttnet_pack.h"        // the policy image (split_pack_body): k_bwd_rows_pair can carry its pack
+#include "ttp2p.h"             // the peer-to-peer gradient exchange of data-parallel ranks: k_adam_soft_p2p reads it
 
 namespace {
 
@@ -1578,6 +1579,100 @@ __global__ __launch_bounds__(256) void k_adam_soft(const AdamTable T, const long
     }
 }
 
+// k_adam_soft for data-parallel ranks WITHOUT a collective launch in front of it (include/ttenv.h: tt_p2p_*): the gradient of
+// element i is the mean over the ranks of G_r[i], read from every rank's exchange block (this rank's own included) and summed
+// in rank order -- the same bits on every rank.  A workgroup takes EPT x 256 consecutive elements of one tensor (few, fat
+// workgroups: each of them waits and acquires once).  Hand-over (per site, epoch = this learn step's number):
+//   publish  the launch's FIRST workgroup: system-scope release, then epoch -> word [site][me] of every rank's block.  The launch
+//            that wrote G_me is the one in front of this one on its stream, so it is complete and written back by now;
+//   wait     every workgroup: until the words [site][0..world) of its OWN block hold the epoch (relaxed system-scope loads of local
+//            fine-grained memory, bounded), then a system-scope acquire;
+//   read     G_r[i] by system-scope loads (never from a cache that could hold the previous step's value of the same address).
+constexpr int P2P_EPT = 8;
+__global__ __launch_bounds__(256) void k_adam_soft_p2p(const AdamTable T, const ttp2p::Args X, const long long *__restrict__ step_dev,
+                                                       const float lr, const float beta1, const float beta2, const float eps,
+                                                       const float weight_decay, const float tau,
+                                                       const float *__restrict__ bias_corr) {
+    const long long step = *step_dev;
+    if (threadIdx.x == 0) {
+        const int epoch = (int)step;
+        if (blockIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            for (int r = 0; r < X.world; ++r)
+                __hip_atomic_store(X.arrive[r] + X.site * ttp2p::MAXR + X.me, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        const int *mine = X.arrive[X.me] + X.site * ttp2p::MAXR;
+        const unsigned long long t0 = wall_clock64();
+        bool gave_up = false;
+        for (int r = 0; r < X.world && !gave_up; ++r) {
+            while (__hip_atomic_load(mine + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch < 0) {
+                __builtin_amdgcn_s_sleep(16);
+                if (wall_clock64() - t0 > X.wait_ticks) {      // never hang: mark (host-visible) and go on; the caller treats the ranks as diverged
+                    __hip_atomic_store(X.gave_up_host, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    gave_up = true;
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    __syncthreads();
+    int ti = 0;
+    while (ti + 1 < T.count && (int)blockIdx.x >= T.block_start[ti + 1]) ++ti;
+    const int base = ((int)blockIdx.x - T.block_start[ti]) * (256 * P2P_EPT) + threadIdx.x;
+    const int n = T.numel[ti];
+    const size_t goff = X.tensor_offset[ti];           // the tensor's place (floats) in the site's flat buffer
+    float bcc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bias_corr) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) bcc[q] = bias_corr[q];
+    }
+    float bc1, bc2;
+    adam_bias_corrections(beta1, beta2, step, bias_corr != nullptr, bcc, bc1, bc2);
+    const float sqrt_bc2 = sqrtf(bc2);
+    const float world_f = (float)X.world;
+    float gsum[P2P_EPT];
+#pragma unroll
+    for (int e = 0; e < P2P_EPT; ++e) gsum[e] = 0.f;
+    for (int r = 0; r < X.world; ++r) {                 // rank order: the same sum on every rank
+        const float *src = X.grad[r] + goff;
+        float part[P2P_EPT];
+#pragma unroll
+        for (int e = 0; e < P2P_EPT; ++e) {
+            const int i = base + e * 256;
+            part[e] = i < n ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < P2P_EPT; ++e) gsum[e] = __fadd_rn(gsum[e], part[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < P2P_EPT; ++e) {
+        const int i = base + e * 256;
+        if (i >= n) continue;
+        const float grad = X.world > 1 ? __fdiv_rn(gsum[e], world_f) : gsum[e];
+        float p = T.p[ti][i];
+        const float g = fmaf(weight_decay, p, grad);
+        const float m = fmaf(beta1, T.m[ti][i], (1.f - beta1) * g);          // exp_avg.lerp_(grad, 1 - beta1)
+        const float v = fmaf(beta2, T.v[ti][i], (1.f - beta2) * g * g);
+        T.m[ti][i] = m;
+        T.v[ti][i] = v;
+        const float denom = sqrtf(v) / sqrt_bc2 + eps;
+        p -= (lr / bc1) * (m / denom);
+        T.p[ti][i] = p;
+        float tg = 0.f;
+        if (T.tgt[ti]) {
+            tg = T.tgt[ti][i];
+            tg = fmaf(tau, p - tg, tg);
+            T.tgt[ti][i] = tg;
+        }
+        if (ti == 4 && (T.img_p || T.img_t)) {
+            const int nn = i / H1, k = i - nn * H1;
+            if (T.img_p) img_store(T.img_p, nn, k, p, true);
+            if (T.img_t && T.tgt[ti]) img_store(T.img_t, nn, k, tg, false);
+        }
+    }
+}
+
 // the image of fc2 from scratch (tt_mlp_fc2_image_pack): one thread per weight; the padding of the buffer is never written
 __global__ __launch_bounds__(256) void k_img_pack(const float *__restrict__ w2, _Float16 *__restrict__ img) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1896,6 +1991,47 @@ int tt_adam_soft_update(int count, float *const *params, const float *const *gra
     }
     T.block_start[count] = blocks;
     hipLaunchKernelGGL(k_adam_soft, dim3(blocks), dim3(256), 0, stream, T, reinterpret_cast<const long long *>(step_dev), lr,
+                       beta1, beta2, eps, weight_decay, tau, bias_corr);
+    return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+int tt_adam_soft_update_p2p(tt_p2p *x, int site, int count, float *const *params, float *const *exp_avg,
+                            float *const *exp_avg_sq, float *const *targets, const int32_t *numel, const int64_t *step_dev,
+                            float lr, float beta1, float beta2, float eps, float weight_decay, float tau,
+                            const tt_fc2_images *images, const float *bias_corr, tt_stream_t stream) {
+    if (!x || site < 0 || site >= x->sites || count <= 0 || count > MAXT || !params || !exp_avg || !exp_avg_sq || !numel || !step_dev)
+        return TT_EINVAL;
+    AdamTable T{};
+    ttp2p::Args X{};
+    if (images && (images->net || images->target)) {       // tensors must then be in tt_mlp_weights order: w2 is number 4
+        if (count < 5 || numel[4] != H2 * H1) return TT_EINVAL;
+        T.img_p = reinterpret_cast<_Float16 *>(images->net);
+        T.img_t = reinterpret_cast<_Float16 *>(images->target);
+    }
+    T.count = count;
+    int blocks = 0;
+    size_t off = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!params[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] <= 0) return TT_EINVAL;
+        T.p[i] = params[i]; T.m[i] = exp_avg[i]; T.v[i] = exp_avg_sq[i];
+        X.tensor_offset[i] = (unsigned)off;
+        T.tgt[i] = targets ? targets[i] : nullptr;
+        T.numel[i] = numel[i];
+        T.block_start[i] = blocks;
+        blocks += (numel[i] + 256 * P2P_EPT - 1) / (256 * P2P_EPT);
+        off += (size_t)numel[i];
+    }
+    T.block_start[count] = blocks;
+    if (off != (size_t)x->numel[site]) return TT_EINVAL;      // the tensors must tile the site's buffer exactly
+    X.world = x->world; X.me = x->rank; X.site = site;
+    for (int r = 0; r < x->world; ++r) {
+        if (!x->attached[r] || !x->block[r]) return TT_EINVAL;      // every peer's block must have been opened (tt_p2p_attach)
+        X.arrive[r] = reinterpret_cast<int *>(x->block[r]);
+        X.grad[r] = reinterpret_cast<const float *>(x->block[r] + x->offset[site]);
+    }
+    X.gave_up_host = x->gave_up_host;
+    X.wait_ticks = x->wait_ticks;
+    hipLaunchKernelGGL(k_adam_soft_p2p, dim3(blocks), dim3(256), 0, stream, T, X, reinterpret_cast<const long long *>(step_dev), lr,
                        beta1, beta2, eps, weight_decay, tau, bias_corr);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }

@@ -30,6 +30,26 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _no_sync():
+    return None
+
+
+class _DeviceMemory:
+    """numel f32 of device memory owned by someone else, for torch.as_tensor (the CUDA array interface, version 2)."""
+
+    def __init__(self, ptr, numel):
+        self.__cuda_array_interface__ = {"shape": (int(numel),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def _device_view(ptr, numel, dev, owner=None):
+    if not ptr:
+        raise RuntimeError("the peer-to-peer exchange returned no gradient buffer")
+    t = torch.as_tensor(_DeviceMemory(ptr, numel), device=dev)
+    assert t.data_ptr() == int(ptr) and t.numel() == numel and t.dtype == torch.float32, "torch copied the external buffer"
+    t._tt_owner = owner                   # (the memory lives as long as the exchange handle does)
+    return t
+
+
 class _NetState:
     """Per-network device buffers: flat gradient (views per parameter, in tt_mlp_weights order), Adam moments."""
 
@@ -40,28 +60,40 @@ class _NetState:
         self.critic = hasattr(net, "action_value")
         n = sum(p.numel() for p in self.params)
         f = dict(dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(n, **f)
         self.m, self.v = torch.zeros(n, **f), torch.zeros(n, **f)
-        self.grads, self.ms, self.vs, off = [], [], [], 0
+        self.ms, self.vs, off = [], [], 0
         for p in self.params:
             k = p.numel()
-            self.grads.append(self.flat_grad[off:off + k].view_as(p))
             self.ms.append(self.m[off:off + k]); self.vs.append(self.v[off:off + k])
             off += k
         self.gstruct = L.TTMlpWeights()
-        for name, g in zip(_FIELDS, self.grads):
-            setattr(self.gstruct, name, g.data_ptr())
         self.gstruct.in_dim, self.gstruct.fc1_dims, self.gstruct.fc2_dims = 23, 400, 300
+        self.bind_flat_grad(torch.zeros(n, **f))
         self.saved_t = dict(xh1=torch.empty((batch, 400), **f), h1=torch.empty((batch, 400), **f),
                             xh2=torch.empty((batch, 300), **f), h2=torch.empty((batch, 300), **f),
                             rstd1=torch.empty(batch, **f), rstd2=torch.empty(batch, **f))
         self.saved = L.TTMlpSaved(**{k: v.data_ptr() for k, v in self.saved_t.items()})
         cnt = len(self.params)
         arr = lambda ts: (C.c_void_p * cnt)(*[t.data_ptr() for t in ts])
-        self.a_p, self.a_g, self.a_m, self.a_v = arr(self.params), arr(self.grads), arr(self.ms), arr(self.vs)
+        self.a_p, self.a_m, self.a_v = arr(self.params), arr(self.ms), arr(self.vs)
         self.a_t = arr(self.targets) if self.targets is not None else None
         self.a_n = (C.c_int32 * cnt)(*[p.numel() for p in self.params])
         self.count = cnt
+
+    def bind_flat_grad(self, flat):
+        """The flat gradient buffer (tt_mlp_weights order) the backward launches write and the optimizer launch / the gradient
+        exchange read: a torch allocation, or a view of a site's buffer of the peer-to-peer exchange (FusedLearner.enable_p2p).
+        Launches captured before a re-bind keep the old addresses: bind before capturing."""
+        assert flat.numel() == sum(p.numel() for p in self.params) and flat.dtype == torch.float32
+        self.flat_grad = flat
+        self.grads, off = [], 0
+        for p in self.params:
+            k = p.numel()
+            self.grads.append(flat[off:off + k].view_as(p))
+            off += k
+        for name, g in zip(_FIELDS, self.grads):
+            setattr(self.gstruct, name, g.data_ptr())
+        self.a_g = (C.c_void_p * len(self.params))(*[t.data_ptr() for t in self.grads])
 
 
 class FusedLearner:
@@ -97,6 +129,7 @@ class FusedLearner:
         self.bias_corr = torch.zeros(8, dtype=torch.float32, device=dev)
         self.z_t = torch.empty((B, 300), **f)          # the target critic's state branch on s' (before the action enters)
         self.grad_sync_critic = self.grad_sync_actor = None
+        self.p2p = None                    # the peer-to-peer gradient exchange (enable_p2p), a tt_p2p handle
         ga, gc = agent.actor.optimizer.param_groups[0], agent.critic.optimizer.param_groups[0]
         self.hyp_actor = (ga["lr"], ga["betas"][0], ga["betas"][1], ga["eps"], ga["weight_decay"])
         self.hyp_critic = (gc["lr"], gc["betas"][0], gc["betas"][1], gc["eps"], gc["weight_decay"])
@@ -182,6 +215,12 @@ class FusedLearner:
 
     def _adam(self, st, hyp, tau):
         lr, b1, b2, eps, wd = hyp
+        if self.p2p is not None:       # the mean of the ranks' gradients is formed INSIDE this launch (include/ttenv.h: tt_p2p_*)
+            L.check_p2p(self.lib.tt_adam_soft_update_p2p(self.p2p, 0 if st.critic else 1, st.count, st.a_p, st.a_m, st.a_v, st.a_t, st.a_n,
+                                                         _p(self.step_dev), lr, b1, b2, eps, wd, tau,
+                                                         C.byref(st.images) if st.images is not None else None,
+                                                         _p(self.bias_corr), self._stream()), self.p2p)
+            return
         L.check(self.lib.tt_adam_soft_update(st.count, st.a_p, st.a_g, st.a_m, st.a_v, st.a_t, st.a_n, _p(self.step_dev),
                                              lr, b1, b2, eps, wd, tau, C.byref(st.images) if st.images is not None else None,
                                              _p(self.bias_corr), self._stream()))
@@ -201,6 +240,59 @@ class FusedLearner:
                 flat.div_(world)
         self.grad_sync_critic = lambda: sync(self.critic.flat_grad)
         self.grad_sync_actor = lambda: sync(self.actor.flat_grad)
+
+    # ---- peer-to-peer gradient exchange ---------------------------------------------------------------------------
+    def enable_p2p(self, group=None, timeout_s=None):
+        """Data-parallel ranks WITHOUT collective launches on learn()'s chain (include/ttenv.h: tt_p2p_*): both flat gradient
+        buffers move into a block of fine-grained device memory that the peers open through an IPC handle, and each rank's Adam
+        launch reads every rank's gradients itself (sum in rank order / world: the same bits on every rank), behind a flag
+        barrier in device memory.  The process group -- any backend -- only carries the 64-byte handles, once.  World size 1
+        (no process group needed) runs the same launches against this rank's own block.  Call before anything is captured."""
+        import os
+        import torch.distributed as dist
+        if timeout_s is None and os.environ.get("TT_P2P_TIMEOUT_S"):
+            timeout_s = float(os.environ["TT_P2P_TIMEOUT_S"])
+        have = dist.is_available() and dist.is_initialized()
+        world, rank = (dist.get_world_size(group), dist.get_rank(group)) if have else (1, 0)
+        if world > L.P2P_MAX_RANKS:
+            raise ValueError(f"the peer-to-peer exchange serves up to {L.P2P_MAX_RANKS} ranks (one node), not {world}")
+        numel = (C.c_int32 * 2)(self.critic.flat_grad.numel(), self.actor.flat_grad.numel())
+        h = C.c_void_p()
+        index = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        L.check_p2p(self.lib.tt_p2p_create(index, rank, world, 2, numel, C.byref(h)))
+        if timeout_s is not None:
+            L.check_p2p(self.lib.tt_p2p_set_timeout(h, float(timeout_s)), h)
+        mine = C.create_string_buffer(L.P2P_HANDLE_BYTES)
+        L.check_p2p(self.lib.tt_p2p_export(h, mine), h)
+        if world > 1:
+            handles = [None] * world
+            dist.all_gather_object(handles, bytes(mine.raw), group=group)
+            for r, hb in enumerate(handles):
+                if r != rank:
+                    L.check_p2p(self.lib.tt_p2p_attach(h, r, C.create_string_buffer(hb, L.P2P_HANDLE_BYTES)), h)
+            dist.barrier(group)            # every rank has opened every block before anyone launches into it
+        self.p2p, self._p2p_group, self._p2p_world = h, group, world
+        for site, st in enumerate((self.critic, self.actor)):
+            st.bind_flat_grad(_device_view(self.lib.tt_p2p_grad(h, site), st.flat_grad.numel(), self.dev, owner=self))
+        self.grad_sync_critic = self.grad_sync_actor = _no_sync       # (learn_batch's data-parallel order: separate Adam launches)
+
+    def p2p_gave_up(self):
+        """0, or the learn step at which this rank's Adam launch stopped waiting for a peer's gradients (it then used whatever the
+        buffers held: the ranks have diverged).  Reads host memory only."""
+        return int(self.lib.tt_p2p_gave_up(self.p2p)) if self.p2p is not None else 0
+
+    def p2p_reset(self):
+        """After the learn-step counter was set back (a resume): arrival words of earlier runs must not satisfy new waits."""
+        if self.p2p is None:
+            return
+        import torch.distributed as dist
+        multi = self._p2p_world > 1
+        torch.cuda.synchronize(self.dev)
+        if multi:
+            dist.barrier(self._p2p_group)
+        L.check_p2p(self.lib.tt_p2p_reset(self.p2p, self._stream()), self.p2p)
+        if multi:
+            dist.barrier(self._p2p_group)
 
     # learn() in the three pieces the two gradient all-reduces cut it into (each piece is pure kernel launches on the
     # current stream, so a data-parallel loop can capture each as a hipGraph and keep only the collectives eager)
@@ -305,6 +397,7 @@ class FusedLearner:
             st = getattr(self, name)
             st.m.copy_(sd[name]["m"]); st.v.copy_(sd[name]["v"])
         self.step_dev.fill_(int(sd["step"]))
+        self.p2p_reset()
 
     # ---- checkpoint interoperability with the torch optimizers ------------------------------------------
     def export_to_optimizers(self):

@@ -496,6 +496,43 @@ int tt_adam_soft_update(int count, float *const *params, const float *const *gra
                         const tt_fc2_images *images /* may be NULL; tensors in tt_mlp_weights order (w2 = index 4) */,
                         const float *bias_corr /* tt_td_input.bias_corr_out or NULL */, tt_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Peer-to-peer gradient exchange of data-parallel ranks (one process per GPU of one node): the mean over the ranks of the
+ * critic's / the actor's gradient at the reference's two optimizer sites (DDPG/DDPG_agent.py:95-104) WITHOUT a collective
+ * launch on learn()'s chain.  Every rank owns one block of fine-grained device memory -- per site a flat f32 gradient
+ * buffer (tt_mlp_weights order: what tt_mlp_backward_weights writes when `grads` points into it) and one arrival word per
+ * rank -- that its peers open through a hipIpcMemHandle; tt_adam_soft_update_p2p is tt_adam_soft_update whose gradient is
+ *      g[i] = (G_0[i] + G_1[i] + ... + G_{world-1}[i]) / world        (summed in rank order: the same bits on every rank)
+ * read straight from the ranks' buffers (xGMI loads at system scope).  Hand-over, per site and learn step t = *step_dev:
+ * the first workgroup of rank r's launch -- which starts only when the launch that wrote G_r (same stream) is complete and
+ * written back -- stores t into word [site][r] of EVERY rank's block (system scope, after a system-scope release); every
+ * workgroup waits until its own block holds t in the words of all ranks, then acquires.  A rank overwrites G_r[site] only
+ * in its next backward launch of that site, which lies behind its update of the OTHER site, whose wait saw every peer past
+ * its reads of this one: two sites used in alternation (critic, actor, critic, ...) need no second barrier.  The wait is
+ * bounded (tt_p2p_set_timeout, default 2 s): a launch that gives up marks a host-visible word (tt_p2p_gave_up) and goes on
+ * with whatever the buffers hold -- the caller must treat the ranks as diverged.  Nothing here needs a process group; the
+ * caller moves the 64-byte handles between the processes (e.g. torch.distributed.all_gather_object on any backend). */
+typedef struct tt_p2p tt_p2p;
+#define TT_P2P_MAX_RANKS 8
+#define TT_P2P_MAX_SITES 4
+#define TT_P2P_HANDLE_BYTES 64
+int tt_p2p_create(int device, int rank, int world, int sites, const int32_t *numel /*[sites] floats per site*/, tt_p2p **out);
+int tt_p2p_destroy(tt_p2p *x);                               /* closes the peers' blocks, frees its own (peers must be done with it) */
+int tt_p2p_export(const tt_p2p *x, void *handle_out /*[TT_P2P_HANDLE_BYTES]*/);
+int tt_p2p_attach(tt_p2p *x, int peer, const void *handle /*[TT_P2P_HANDLE_BYTES] of rank `peer`*/);
+float *tt_p2p_grad(const tt_p2p *x, int site);                /* this rank's gradient buffer of `site` (device memory), or NULL */
+int tt_p2p_reset(tt_p2p *x, tt_stream_t stream);              /* own arrival words back to 0 (a step counter set back: resume);
+                                                                 the caller keeps every rank out of the exchange meanwhile */
+int tt_p2p_set_timeout(tt_p2p *x, double seconds);
+int tt_p2p_gave_up(const tt_p2p *x);                          /* 0, or the step whose wait was abandoned; reads host memory only */
+const char *tt_p2p_last_error(const tt_p2p *x);
+/* tt_adam_soft_update with the gradient taken from the exchange (above).  numel[0..count) must add up to the site's size;
+ * every rank of the exchange must launch it for the same site with the same *step_dev. */
+int tt_adam_soft_update_p2p(tt_p2p *x, int site, int count, float *const *params, float *const *exp_avg,
+                            float *const *exp_avg_sq, float *const *targets, const int32_t *numel, const int64_t *step_dev,
+                            float lr, float beta1, float beta2, float eps, float weight_decay, float tau,
+                            const tt_fc2_images *images, const float *bias_corr, tt_stream_t stream);
+
 /* target = rewards + gamma * critic_value_ with critic_value_[done] = 0 (DDPG_agent.py:89-93); also advances the
  * learn-step counter *step_dev (may be NULL) that tt_adam_soft_update reads. */
 int tt_td_target(int n, const float *reward, const float *q_next, const uint8_t *done, float gamma, float *y,

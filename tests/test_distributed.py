@@ -289,6 +289,175 @@ def test_rccl_n_rank_loop(tmp_path, gpu_device, world):
     assert torch.isfinite(flats[0][0]).all()
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Peer-to-peer gradient exchange (include/ttenv.h: tt_p2p_*): no collective on learn()'s chain; each rank's Adam launch reads
+# the peers' flat gradient buffers through IPC-opened device memory behind a flag barrier.  Two processes on ONE GPU prove the
+# protocol (handles, barrier, epochs, graphs); only its speed over xGMI needs a second GPU.
+def _p2p_learner_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    from ddpg_trucktrailer_amd.agent import Agent
+    from ddpg_trucktrailer_amd.fused_learn import FusedLearner
+    from test_learner import _load_init
+    z = np.load(F5, allow_pickle=False)
+    torch.manual_seed(100 + rank)
+    agent = Agent(alpha=1e-4, beta=1e-3, input_dims=(23,), tau=1e-3, n_actions=1, batch_size=128, device=dev, replay=False)
+    if rank == 0:
+        _load_init(agent, z)
+    agent.enable_data_parallel()                 # broadcast of rank 0's weights (the control plane: gloo)
+    agent.update_network_parameters(tau=1)
+    fl = FusedLearner(agent, 128)
+    fl.enable_p2p()
+    assert fl.p2p is not None and fl.critic.flat_grad.data_ptr() != 0
+    half = slice(rank * 128, (rank + 1) * 128)
+    f = lambda k: torch.tensor(z[k][half], dtype=torch.float, device=dev)
+    d8 = torch.tensor(z["batch_dones"][half].astype(np.uint8), device=dev)
+    grads = []
+    for _ in range(3):
+        fl.learn_batch(f("batch_states"), f("batch_actions"), f("batch_rewards"), f("batch_states_"), d8)
+        torch.cuda.synchronize()
+        grads.append(torch.cat([fl.critic.flat_grad, fl.actor.flat_grad]).cpu())      # this rank's OWN half-batch gradients
+    assert fl.p2p_gave_up() == 0
+    flat = torch.cat([p.detach().reshape(-1) for net in agent._nets() for p in net.parameters()]).cpu()
+    torch.save({"flat": flat, "grads": grads}, os.path.join(out_dir, f"p2p_rank{rank}.pt"))
+    if rank == 0:
+        torch.save({n: {k: v.cpu() for k, v in getattr(agent, n).state_dict().items()}
+                    for n in ("actor", "critic", "target_actor", "target_critic")}, os.path.join(out_dir, "p2p_state.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_p2p_two_rank_fused_learner_matches_reference_full_batch(tmp_path, gpu_device):
+    """Two ranks x half batches of fixture F5 with the peer-to-peer exchange == the reference's own full-batch learn() after three
+    steps (the mean of the two half-batch mean-gradients is the full-batch mean-gradient; sites of DDPG/DDPG_agent.py:95-104);
+    ranks bit-identical although their own gradients differ."""
+    port = _free_port()
+    mp.start_processes(_p2p_learner_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    a = torch.load(tmp_path / "p2p_rank0.pt", weights_only=True)
+    b = torch.load(tmp_path / "p2p_rank1.pt", weights_only=True)
+    assert torch.equal(a["flat"], b["flat"]), "ranks diverged"
+    assert not torch.equal(a["grads"][0], b["grads"][0])          # each rank kept its own half-batch gradient in its own block
+    z = np.load(F5, allow_pickle=False)
+    state = torch.load(tmp_path / "p2p_state.pt", weights_only=True)
+    stride = int(z["sample_stride"])
+    for name, sd in state.items():
+        for k, v in sd.items():
+            got = v.numpy()
+            if k == "fc2.weight":
+                got = got.reshape(-1)[::stride]
+            ref = z[f"after3/{name}/{k}"]
+            assert np.abs(got - ref).max() <= 4e-5 * max(1e-1, np.abs(ref).max()) + 1e-6, (name, k)
+
+
+def _p2p_loop_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", TT_P2P_TIMEOUT_S="20")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    flats = []
+    steps = 4 + 20 + 4 + 1 + 4
+    # p2p with graphs of 20 / 4 / 1 steps, p2p eager, the collective structure (gloo SUM / world) as three graph segments per step
+    variants = [dict(graph_steps=20, dp_exchange="p2p"), dict(graph_steps=0, dp_exchange="p2p"), dict(graph_steps=4, dp_exchange="collective")]
+    if world == 1:
+        variants.append(dict(graph_steps=20, data_parallel=False))
+    for kw in variants:
+        env = TruckTrailerVecEnv(1024, device="cuda:0")
+        env.reset(seed=27 + rank)
+        kw.setdefault("data_parallel", True)
+        loop = DDPGRollout(env, batch_size=128, replay_slots=8, seed=27 + rank, world_size=world, **kw)
+        dist.barrier()                     # (the ranks start a variant together: the exchange's wait is bounded)
+        loop.run(steps)
+        torch.cuda.synchronize()
+        if kw.get("dp_exchange") == "p2p":
+            assert loop.dp and loop.dp_single_graph and loop.learner.p2p is not None and loop.learner.p2p_gave_up() == 0
+            assert (loop.graphG is not None) == (kw["graph_steps"] > 0) and loop.dp_graphs is None
+        assert loop.handover_gave_up == []
+        flats.append(torch.cat([p.detach().reshape(-1) for net in loop.agent._nets() for p in net.parameters()]).cpu())
+        env.close()
+    torch.save(flats, os.path.join(out_dir, f"p2p_loop{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_p2p_loop_matches_the_collective_loop(tmp_path, gpu_device, world):
+    """The N-env loop with the peer-to-peer exchange, `world` gloo-launched ranks on ONE GPU: graphs (20 / 4 / 1 whole steps, the
+    exchange inside them) == eager steps bit for bit; every rank ends with the same bits; and the result equals the loop whose
+    gradients go through the process group's all-reduce -- bitwise at these world sizes (a sum of two is order-free, / 2 exact;
+    world 1: the identity), to rounding beyond.  World size 1 also equals the single-rank loop."""
+    port = _free_port()
+    mp.start_processes(_p2p_loop_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    flats = [torch.load(tmp_path / f"p2p_loop{r}.pt", weights_only=True) for r in range(world)]
+    for r in range(1, world):
+        assert all(torch.equal(x, y) for x, y in zip(flats[0], flats[r])), "ranks diverged"
+    a = flats[0]
+    assert torch.isfinite(a[0]).all()
+    assert torch.equal(a[0], a[1]), "p2p graphs differ from p2p eager steps"
+    assert torch.equal(a[0], a[2]), "p2p exchange differs from the collective (all-reduce) structure"
+    if world == 1:
+        assert torch.equal(a[0], a[3]), "data-parallel p2p structure at world size 1 differs from the single-rank loop"
+
+
+_P2P_STALL = r"""
+import os, sys, time
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from ddpg_trucktrailer_amd.rollout import DDPGRollout
+from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+env = TruckTrailerVecEnv(1024, device="cuda:0")
+env.reset(seed=27 + rank)
+loop = DDPGRollout(env, batch_size=128, replay_slots=8, seed=27 + rank, world_size=world, graph_steps=4, data_parallel=True, dp_exchange="p2p")
+loop.run(9)
+torch.cuda.synchronize()
+dist.barrier()
+print("in step", rank, flush=True)
+if rank == 1:
+    time.sleep(8)              # rank 1 falls behind by more than the exchange's time limit
+    print("rank 1 done sleeping", flush=True)
+    os._exit(0)
+try:
+    loop.run(8)
+    loop.state_dict()
+    print("NOT NOTICED", flush=True)
+except RuntimeError as exc:
+    print("noticed:", exc, flush=True)
+os._exit(0)
+"""
+
+
+@pytest.mark.gpu
+def test_p2p_wait_is_bounded_and_a_give_up_is_an_error(gpu_device):
+    """A rank whose peer stops taking part: its Adam launch waits for the peer's arrival word for the exchange's time limit (1 s
+    here), marks a host-visible word and ends -- the GPU is never hung -- and the loop raises at its next look (the ranks'
+    weights have diverged; there is no fallback for that)."""
+    import subprocess
+    import time
+    port = _free_port()
+    procs = []
+    t0 = time.monotonic()
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TT_P2P_TIMEOUT_S="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _P2P_STALL % ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    took = time.monotonic() - t0
+    assert "in step 0" in outs[0][0] and "in step 1" in outs[1][0], outs
+    assert "noticed:" in outs[0][0] and "gave up waiting for a peer's gradients" in outs[0][0], outs[0]
+    assert "NOT NOTICED" not in outs[0][0]
+    assert took < 200
+
+
 def test_bench_refuses_fewer_gpus_than_ranks():
     """`python bench.py --gpus N` starts N ranks itself; with fewer than N GPUs visible it prints no line and exits 2."""
     import subprocess
