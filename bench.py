@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 
 B_ALG = 313            # algorithmic bytes per env-step
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")      # newest first
 # the two gradient all-reduce sites of a data-parallel learn() (DDPG_agent.py:95-104): flat f32 buffers of these sizes
 GRAD_NUMEL = {"critic": 132201, "actor": 131601}
 
@@ -469,6 +469,20 @@ def main():
     # ~30 ms of work to come back (tools/driver_form.py: the first 2 ms region after a 10 ms idle runs 5-9 % slow), which a
     # warm-up of a few steps does not provide.  Untimed vector steps of the same loop, counted in config.setup_vector_steps;
     # every rank runs the same number (the data-parallel loop holds collectives).
+    # What the driver's form gives WITHOUT the settle phase below (rounds 1-2 measured exactly this): W warm-up steps right after
+    # the idle of graph capture, then K steps between synchronizes -- reported beside the headline as timing.cold_ms_per_step.
+    cold_ms = None
+    if ddpg_loop is not None:
+        wd.enter("cold region (no settle phase)")
+        run(args.warmup)
+        sync_all()
+        t0 = time.perf_counter()
+        run(args.steps)
+        sync_all()
+        cold = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(cold, op=dist.ReduceOp.MAX)
+        cold_ms = float(cold.item()) / args.steps * 1e3
     settle_steps = 0
     if args.settle_ms is None:     # (the env workload's 0.2 ms regions gain nothing: 9.2 -> 8.9 us per step on the GPU's clock, but
         args.settle_ms = float(os.environ.get("TT_BENCH_SETTLE_MS", "100")) if ddpg_loop is not None else 0.0   # +15 us of host time)
@@ -565,6 +579,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": dict({"workload": workload, "n_envs_per_gpu": n, "n_envs_total": n * world}, **extra),
         "timing": {"wall_ms_per_step": elapsed / args.steps * 1e3, "event_ms_per_step": event_ms / args.steps,
+                   "cold_ms_per_step": cold_ms,      # the same K steps after W warm-up steps BEFORE the settle phase (config.setup_settle)
                    "repeats": len(reps), "repeat_event_ms_per_step": reps,
                    "median_ms_per_step": (sorted(reps)[len(reps) // 2] if reps else None),
                    "spread_ms_per_step": ((max(reps) - min(reps)) if reps else None)},

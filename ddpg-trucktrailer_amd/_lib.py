@@ -204,7 +204,7 @@ def check_p2p(rc, handle=None):
         raise TTError(f"libttenv p2p error {rc}: {msg.decode() if msg else '?'}")
 
 
-P2P_HANDLE_BYTES, P2P_MAX_RANKS = 64, 8
+P2P_HANDLE_BYTES, P2P_MAX_RANKS = 128, 8
 
 
 def default_params(variant=0):

@@ -39,5 +39,23 @@ def build(force=False, verbose=False, defines=(), out=None):
     return out
 
 
+# diagnostic builds of the same sources (A/B timing and stamps through TT_LIB_PATH; tools/*.py, tools/profile_round*.sh)
+VARIANTS = {
+    "stamps": (("TT_STAMPS",), os.path.join(ROOT, "tools", "dbg", "libttenv_stamps.so")),    # wall-clock stamps per workgroup / phase
+}
+
+
+def build_variant(name, verbose=False):
+    defines, out = VARIANTS[name]
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if os.path.exists(out) and all(os.path.getmtime(p) <= os.path.getmtime(out) for p in SRC + HDR):
+        return out
+    return build(force=True, verbose=verbose, defines=defines, out=out)
+
+
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":
+        print(build_variant(sys.argv[2], verbose=True))
+    else:
+        print(build(force=True, verbose=True))

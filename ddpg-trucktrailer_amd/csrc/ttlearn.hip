@@ -208,6 +208,7 @@ __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 
 __device__ __forceinline__ float4 f4_ld(const float *p, const bool ok) {     // 16-byte aligned p; zeros where !ok
     return ok ? *reinterpret_cast<const float4 *>(p) : f4_zero();
 }
+__device__ __forceinline__ float4 f4_ldu(const float *p) { return *reinterpret_cast<const float4 *>(p); }     // 16-byte aligned p
 __device__ __forceinline__ float f4_sum(const float4 v) { return (v.x + v.y) + (v.z + v.w); }
 using h2v = __attribute__((ext_vector_type(2))) _Float16;
 // four f32 -> their f16 pieces (round to nearest): h = rn16(x), m = rn16(x - h), as two 8-byte groups
@@ -230,7 +231,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
                                                const float *__restrict__ action, const Weights &W,
                                                float *__restrict__ out, const Saved &sv, float *__restrict__ dq_da,
                                                float *__restrict__ z_state, float *__restrict__ h1_s,
-                                               float *__restrict__ z_s, const int row0,
+                                               float *__restrict__ z_s, float *__restrict__ w1_s, const int row0,
                                                const float *__restrict__ obs_row_lane = nullptr,
                                                const bool act_given = false, const float act_row0 = 0.f,
                                                const float act_row1 = 0.f) {
@@ -248,56 +249,73 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
     // move a load across, so each would cost an exposed L2 round trip there
     // (layer 1's vectors here; layer 2's are requested where layer 2 starts and land behind its products)
     float4 pb1[RV], pg1[RV], pbe1[RV], pb2[RV], pg2[RV], pbe2[RV], pw3[RV], pwa[RV], pba[RV];
+    // EVERY load of this phase is unconditional, from a clamped address, and issued before the first MFMA (a value that must be
+    // zero is zeroed afterwards).  Guarded loads (`k < IN ? w1[..] : 0`) made the compiler wrap each in a saved exec mask and emit
+    // layer 1 tile by tile -- loads, wait, six MFMAs, the next tile's loads ...: four dependent round trips to L2 for a K = 23
+    // product (3.8 us of the row kernel; round 3's stamps), and one more for the second group of per-column vectors.
 #pragma unroll
     for (int i = 0; i < RV; ++i) {
-        const int c = rv_col(lane, i);
-        const bool r1 = c < H1;
-        pb1[i] = f4_ld(W.b1 + c, r1); pg1[i] = f4_ld(W.g1 + c, r1); pbe1[i] = f4_ld(W.be1 + c, r1);
+        const int c = rv_col(lane, i), cc = c < H1 ? c : 0;       // (values beyond column 399 are never used)
+        pb1[i] = *reinterpret_cast<const float4 *>(W.b1 + cc); pg1[i] = *reinterpret_cast<const float4 *>(W.g1 + cc);
+        pbe1[i] = *reinterpret_cast<const float4 *>(W.be1 + cc);
     }
     // ---- layer 1 (K = 23): operands straight from global; this wave's column tiles t = wave, wave+NW, ...
     f32x4 acc1[MT1];
 #pragma unroll
     for (int i = 0; i < MT1; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int GU_F = 3;
+    const bool img = W.img != nullptr;                     // (uniform over the launch)
+    const int nt_f = (NT2 - wave + NW - 1) / NW;          // layer-2 tiles of this wave: 3 (waves 0..3) or 2
+    f16x8 bpre[GU_F][MT2][2];
     {
+        // fc1 [400,23] reaches the workgroup ONCE, as 2300 coalesced float4 (36.8 KB), through LDS: read in place -- each lane its
+        // six values of each of its wave's tiles, rows 92 bytes apart -- it cost 24 four-byte loads per lane that touch 12-16
+        // cache lines each, and the CU's one address pipe was busy with them for ~2 us (8 waves x 36 such loads): layer 1 of a
+        // K = 23 product took 3.1-3.8 us.  The observation rows (6 loads per lane) are still read in place.
         float a[INP / 4];
+        const float *arow = obs_row_lane ? obs_row_lane : obs + (size_t)min(row0 + l15, n - 1) * IN;
+        const bool arow_ok = row0 + l15 < n;
+        constexpr int W1_F4 = H1 * IN / 4, W1_PER = (W1_F4 + 64 * NW - 1) / (64 * NW);
+        float4 wv[W1_PER];
 #pragma unroll
-        for (int ks = 0; ks < INP / 4; ++ks) {
-            const int k = ks * 4 + l4;
-            a[ks] = (k < IN && row0 + l15 < n) ? (obs_row_lane ? obs_row_lane[k] : obs[(size_t)(row0 + l15) * IN + k]) : 0.f;
-        }
+        for (int q = 0; q < W1_PER; ++q) wv[q] = f4_ldu(W.w1 + 4 * min(tid + 64 * NW * q, W1_F4 - 1));
+#pragma unroll
+        for (int ks = 0; ks < INP / 4; ++ks) a[ks] = arow[min(ks * 4 + l4, IN - 1)];
+#pragma unroll
+        for (int q = 0; q < W1_PER; ++q)
+            if (tid + 64 * NW * q < W1_F4) *reinterpret_cast<float4 *>(w1_s + 4 * (tid + 64 * NW * q)) = wv[q];
+        lds_barrier();
+#pragma unroll
+        for (int ks = 0; ks < INP / 4; ++ks) a[ks] = (ks * 4 + l4 < IN && arow_ok) ? a[ks] : 0.f;
 #pragma unroll
         for (int i = 0; i < MT1; ++i) {
-            const int t = wave + NW * i;
-            if (t < NT1) {
+            if (wave + NW * i < NT1) {
+                const float *wr = w1_s + ((wave + NW * i) * 16 + l15) * IN;
                 float b[INP / 4];
 #pragma unroll
                 for (int ks = 0; ks < INP / 4; ++ks) {
-                    const int k = ks * 4 + l4;
-                    b[ks] = k < IN ? W.w1[(t * 16 + l15) * IN + k] : 0.f;
+                    const float v = wr[min(ks * 4 + l4, IN - 1)];
+                    b[ks] = ks * 4 + l4 < IN ? v : 0.f;          // (only k = 23, the padding of the last k4 group, is not)
                 }
 #pragma unroll
                 for (int ks = 0; ks < INP / 4; ++ks) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b[ks], acc1[i], 0, 0, 0);
             }
         }
+        // The first group of fc2 fragments (three k32 steps of this wave's tiles, straight from L2) is requested HERE: it does not
+        // depend on the activations, and requested where layer 2 starts it cost that phase one exposed round trip.  (Requested
+        // in front of layer 1 it delays the other waves' layer-1 operands: 144 KB through the same address pipe.)
+        if (img) {
+#pragma unroll
+            for (int u = 0; u < GU_F; ++u)
+#pragma unroll
+                for (int i = 0; i < MT2; ++i) {
+                    const _Float16 *bq = W.img + ((size_t)min(wave + NW * i, NT2 - 1) * FW_STEPS * 64 + lane) * 8 + 512 * u;
+                    bpre[u][i][0] = *reinterpret_cast<const f16x8 *>(bq);
+                    bpre[u][i][1] = *reinterpret_cast<const f16x8 *>(bq + IMG_FWD);
+                }
+        }
     }
     STAMP(1);
-    // The first group of fc2 fragments (three k32 steps of this wave's tiles, straight from L2) is requested HERE: it does not
-    // depend on the activations, and requested where layer 2 starts it cost that phase one exposed L2 round trip (~1 us)
-    constexpr int GU_F = 3;
-    const bool img = W.img != nullptr;                     // (uniform over the launch)
-    const int nt_f = (NT2 - wave + NW - 1) / NW;          // layer-2 tiles of this wave: 3 (waves 0..3) or 2
-    f16x8 bpre[GU_F][MT2][2];
-    if (img) {
-#pragma unroll
-        for (int u = 0; u < GU_F; ++u)
-#pragma unroll
-            for (int i = 0; i < MT2; ++i)
-                if (i < nt_f) {
-                    const _Float16 *b = W.img + ((size_t)min(wave + NW * i, NT2 - 1) * FW_STEPS * 64 + lane) * 8 + 512 * u;
-                    bpre[u][i][0] = *reinterpret_cast<const f16x8 *>(b);
-                    bpre[u][i][1] = *reinterpret_cast<const f16x8 *>(b + IMG_FWD);
-                }
-    }
     // accumulator element [i][r] is row l4*4 + r, column (wave + NW*i)*16 + l15
 #pragma unroll
     for (int i = 0; i < MT1; ++i) {
@@ -374,11 +392,13 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
     auto load_l2_vectors = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < RV; ++i) {
-            const int c = rv_col(lane, i);
-            const bool r2 = c < H2;
-            pb2[i] = f4_ld(W.b2 + c, r2); pg2[i] = f4_ld(W.g2 + c, r2); pbe2[i] = f4_ld(W.be2 + c, r2);
-            pw3[i] = f4_ld(W.w3 + c, r2);
-            pwa[i] = f4_ld(W.wa + c, CRITIC && r2); pba[i] = f4_ld(W.ba + c, CRITIC && r2);
+            // (unconditional, from a clamped column: a guarded load costs a saved exec mask and, worse, its own wait -- see layer 1;
+            // every use of these values is guarded by c < H2)
+            const int c = rv_col(lane, i), cc = c < H2 ? c : 0;
+            pb2[i] = f4_ldu(W.b2 + cc); pg2[i] = f4_ldu(W.g2 + cc); pbe2[i] = f4_ldu(W.be2 + cc);
+            pw3[i] = f4_ldu(W.w3 + cc);
+            if (CRITIC) { pwa[i] = f4_ldu(W.wa + cc); pba[i] = f4_ldu(W.ba + cc); }
+            else { pwa[i] = f4_zero(); pba[i] = f4_zero(); }
         }
     };
 
@@ -573,8 +593,9 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_small(const int n, const float 
                                                    float *__restrict__ z_state) {
     __shared__ __attribute__((aligned(16))) float h1_s[H1S_FLOATS];
     __shared__ __attribute__((aligned(16))) float z_s[TR * DS];
+    __shared__ __attribute__((aligned(16))) float w1_s[H1 * IN];
     KBEGIN(3);
-    fwd_small_body<CRITIC>(n, obs, action, W, out, sv, dq_da, z_state, h1_s, z_s, blockIdx.x * TR);
+    fwd_small_body<CRITIC>(n, obs, action, W, out, sv, dq_da, z_state, h1_s, z_s, w1_s, blockIdx.x * TR);
     KEND(3);
 }
 
@@ -604,6 +625,7 @@ struct FwdJobs {
 __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
     __shared__ __attribute__((aligned(16))) float h1_s[H1S_FLOATS];
     __shared__ __attribute__((aligned(16))) float z_s[TR * DS];
+    __shared__ __attribute__((aligned(16))) float w1_s[H1 * IN];
     const int job = blockIdx.x / J.blocks_per_job, row0 = (blockIdx.x - job * J.blocks_per_job) * TR;
     const FwdJob &q = J.j[job];
     KBEGIN(0);
@@ -655,9 +677,9 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
         }
     }
     if (q.critic)
-        fwd_small_body<true>(J.n, q.obs, q.action, q.W, q.out, q.sv, q.dq_da, q.z_state, h1_s, z_s, row0, orow, have_act, act_r0, act_r1);
+        fwd_small_body<true>(J.n, q.obs, q.action, q.W, q.out, q.sv, q.dq_da, q.z_state, h1_s, z_s, w1_s, row0, orow, have_act, act_r0, act_r1);
     else
-        fwd_small_body<false>(J.n, q.obs, q.action, q.W, q.out, q.sv, nullptr, nullptr, h1_s, z_s, row0, orow);
+        fwd_small_body<false>(J.n, q.obs, q.action, q.W, q.out, q.sv, nullptr, nullptr, h1_s, z_s, w1_s, row0, orow);
     KEND(0);
 }
 
@@ -728,36 +750,45 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
     float rs[RPW], gin[RPW], yin[RPW], outv[RPW], mut[RPW], rt[RPW], b3t = 0.f;
     bool dt[RPW];
     const bool with_td = CRITIC && td.z_state;               // (uniform over the launch)
+    // Every load below is unconditional, from a clamped row / column (a value that must be zero is zeroed afterwards; most uses
+    // are guarded anyway): guarded loads made the compiler emit this phase as a chain of exec-masked blocks, each with its own
+    // wait -- five dependent round trips to L2 in front of the first arithmetic (5.0 us for this phase in round 3's stamps).
+    // `with_td` is uniform over the launch: a scalar branch around loads that would dereference null pointers.
 #pragma unroll
     for (int i = 0; i < RV; ++i) {
-        const int c = rv_col(lane, i);
-        const bool real = c < H2;
-        w3c[i] = f4_ld(W.w3 + c, real); g2c[i] = f4_ld(W.g2 + c, real);
-        wat[i] = f4_ld(td.wa + c, with_td && real); bat[i] = f4_ld(td.ba + c, with_td && real);
-        w3t[i] = f4_ld(td.w3 + c, with_td && real);
+        const int c = rv_col(lane, i), cc = c < H2 ? c : 0;
+        w3c[i] = f4_ldu(W.w3 + cc); g2c[i] = f4_ldu(W.g2 + cc);
+        wat[i] = f4_zero(); bat[i] = f4_zero(); w3t[i] = f4_zero();
     }
-    if (with_td) b3t = td.b3[0];
+    if (with_td) {
+#pragma unroll
+        for (int i = 0; i < RV; ++i) {
+            const int c = rv_col(lane, i), cc = c < H2 ? c : 0;
+            wat[i] = f4_ldu(td.wa + cc); bat[i] = f4_ldu(td.ba + cc); w3t[i] = f4_ldu(td.w3 + cc);
+        }
+        b3t = td.b3[0];
+    }
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
-        const int row = row0 + wave * RPW + rr;
-        const bool ok = row < n;
-        rs[rr] = ok ? sv.rstd2[row] : 0.f;
-        outv[rr] = (ok && mode != 0) || (ok && !CRITIC) ? out[row] : 0.f;
-        gin[rr] = !ok ? 0.f : (mode == 0 ? d_out[row] : (mode == 2 ? aux[row] : 0.f));
-        yin[rr] = (ok && mode == 1 && !with_td) ? y[row] : 0.f;
-        mut[rr] = (ok && with_td) ? td.mu_t[row] : 0.f;
-        rt[rr] = (ok && with_td) ? td.r[row] : 0.f;
-        dt[rr] = (ok && with_td) ? td.done[row] != 0 : false;
+        const int row = row0 + wave * RPW + rr, rowc = min(row, n - 1);
+        rs[rr] = sv.rstd2[rowc];
+        outv[rr] = (mode != 0 || !CRITIC) ? out[rowc] : 0.f;
+        gin[rr] = mode == 0 ? d_out[rowc] : (mode == 2 ? aux[rowc] : 0.f);
+        yin[rr] = (mode == 1 && !with_td) ? y[rowc] : 0.f;
+        mut[rr] = 0.f; rt[rr] = 0.f; dt[rr] = false;
+        if (with_td) { mut[rr] = td.mu_t[rowc]; rt[rr] = td.r[rowc]; dt[rr] = td.done[rowc] != 0; }
 #pragma unroll
         for (int i = 0; i < RV; ++i) {
             const int c = rv_col(lane, i);
-            const bool real = ok && c < H2;
-            const size_t q = (size_t)row * H2 + c;
-            h2v[rr][i] = f4_ld(sv.h2 + q, real);
-            xh[rr][i] = f4_ld(sv.xh2 + q, real);
-            zt[rr][i] = f4_ld(td.z_state + q, real && with_td);
+            const size_t q = (size_t)rowc * H2 + (c < H2 ? c : 0);
+            h2v[rr][i] = f4_ldu(sv.h2 + q);
+            xh[rr][i] = f4_ldu(sv.xh2 + q);
+            zt[rr][i] = with_td ? f4_ldu(td.z_state + q) : f4_zero();
         }
     }
+#pragma unroll
+    for (int i = 0; i < RV; ++i)                               // the TD dot product runs over every lane's columns: none beyond 299
+        if (!(rv_col(lane, i) < H2)) w3t[i] = f4_zero();
     if (with_td && blockIdx.x == 0 && tid == 0 && !td.separate_tick) {
         if (td.step_dev) *td.step_dev += 1;
         if (td.window_dev) *td.window_dev += 1;      // a pipelined loop's sampling window moves on (read by LATER launches only)
@@ -872,15 +903,16 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
     // what phase C needs from memory is requested now, so that it arrives behind phase B's MFMAs (and, as in phase A,
     // before any store of phase C)
     float4 hv[4], xv[4];
-    const float4 gm = gok ? *reinterpret_cast<const float4 *>(W.g1 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (unconditional, from clamped rows / columns, as in phase A: phase C uses them under `gok && row < n` only)
+    const int c0c = gok ? c0 : 0;
+    const float4 gm = f4_ldu(W.g1 + c0c);
     float rs1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = row0 + l4 * 4 + r;
-        const bool ok = gok && row < n;
-        hv[r] = ok ? *reinterpret_cast<const float4 *>(sv.h1 + (size_t)row * H1 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        xv[r] = ok ? *reinterpret_cast<const float4 *>(sv.xh1 + (size_t)row * H1 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        rs1[r] = ok ? sv.rstd1[row] : 0.f;
+        const int rowc = min(row0 + l4 * 4 + r, n - 1);
+        hv[r] = f4_ldu(sv.h1 + (size_t)rowc * H1 + c0c);
+        xv[r] = f4_ldu(sv.xh1 + (size_t)rowc * H1 + c0c);
+        rs1[r] = sv.rstd1[rowc];
     }
     if (img && wave < NG) {
         // the image's backward half: this wave's four tiles (= its 64-column group) in k32 steps over n; A = the dX2 planes
@@ -1194,13 +1226,22 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
     if (threadIdx.x == 0) g_blk[blockIdx.x][0] = wall_clock64();
 #endif
     WST(8);
+    // The step count and Adam's bias corrections are needed at the very end, but wherever they are read the compiler turns the two
+    // wave-uniform reads into SCALAR loads through pointers that are themselves kernel arguments and hoists them to the top:
+    // kernarg -> pointer -> value, two dependent round trips of the scalar cache behind ONE counter (lgkmcnt), in front of the
+    // first operand load of every workgroup (~0.7 us of the 1.5 us "entry -> operand loads issued" of round 3's stamps).  With
+    // the pointers laundered into vector registers they are ordinary vector loads: asynchronous, first in the queue.
     long long step_count = 0;
     float bcc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (A.on) {
-        step_count = *A.step_dev;
+        const long long *sp = A.step_dev;
+        asm volatile("" : "+v"(sp));
+        step_count = *sp;
         if (A.bias_corr) {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) bcc[i] = A.bias_corr[i];
+            const float *bp = A.bias_corr;
+            asm volatile("" : "+v"(bp));
+            const float4 b4 = *reinterpret_cast<const float4 *>(bp);
+            bcc[0] = b4.x; bcc[1] = b4.y; bcc[2] = b4.z; bcc[3] = b4.w; bcc[4] = bp[4];
         }
     }
     auto bias_corrections = [&](float &bc1, float &sqrt_bc2) __attribute__((always_inline)) {
@@ -1588,16 +1629,40 @@ __global__ __launch_bounds__(256) void k_adam_soft(const AdamTable T, const long
 //   wait     every workgroup: until the words [site][0..world) of its OWN block hold the epoch (relaxed system-scope loads of local
 //            fine-grained memory, bounded), then a system-scope acquire;
 //   read     G_r[i] by system-scope loads (never from a cache that could hold the previous step's value of the same address).
-constexpr int P2P_EPT = 8;
+#ifndef TT_P2P_EPT
+#define TT_P2P_EPT 4
+#endif
+constexpr int P2P_EPT = TT_P2P_EPT;
 __global__ __launch_bounds__(256) void k_adam_soft_p2p(const AdamTable T, const ttp2p::Args X, const long long *__restrict__ step_dev,
                                                        const float lr, const float beta1, const float beta2, const float eps,
                                                        const float weight_decay, const float tau,
                                                        const float *__restrict__ bias_corr) {
     const long long step = *step_dev;
+    int ti = 0;
+    while (ti + 1 < T.count && (int)blockIdx.x >= T.block_start[ti + 1]) ++ti;
+    const int base = ((int)blockIdx.x - T.block_start[ti]) * (256 * P2P_EPT) + threadIdx.x;
+    const int n = T.numel[ti];
+    // everything that does not depend on the exchange is requested first -- this rank's parameters, Adam moments, targets, bias
+    // corrections -- so that those loads fly while the workgroup waits for the arrival words
+    float pv[P2P_EPT], mv[P2P_EPT], vv[P2P_EPT], tv[P2P_EPT];
+    const bool has_t = T.tgt[ti] != nullptr;
+#pragma unroll
+    for (int e = 0; e < P2P_EPT; ++e) {
+        const int i = min(base + e * 256, n - 1);
+        pv[e] = T.p[ti][i]; mv[e] = T.m[ti][i]; vv[e] = T.v[ti][i];
+        tv[e] = has_t ? T.tgt[ti][i] : 0.f;
+    }
+    float bcc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bias_corr) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) bcc[q] = bias_corr[q];
+    }
     if (threadIdx.x == 0) {
         const int epoch = (int)step;
         if (blockIdx.x == 0) {
+#ifndef TT_P2P_NOFENCE
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+#endif
             for (int r = 0; r < X.world; ++r)
                 __hip_atomic_store(X.arrive[r] + X.site * ttp2p::MAXR + X.me, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -1606,7 +1671,7 @@ __global__ __launch_bounds__(256) void k_adam_soft_p2p(const AdamTable T, const 
         bool gave_up = false;
         for (int r = 0; r < X.world && !gave_up; ++r) {
             while (__hip_atomic_load(mine + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch < 0) {
-                __builtin_amdgcn_s_sleep(16);
+                __builtin_amdgcn_s_sleep(8);
                 if (wall_clock64() - t0 > X.wait_ticks) {      // never hang: mark (host-visible) and go on; the caller treats the ranks as diverged
                     __hip_atomic_store(X.gave_up_host, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     gave_up = true;
@@ -1614,23 +1679,12 @@ __global__ __launch_bounds__(256) void k_adam_soft_p2p(const AdamTable T, const 
                 }
             }
         }
+#ifndef TT_P2P_NOFENCE
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+#endif
     }
     __syncthreads();
-    int ti = 0;
-    while (ti + 1 < T.count && (int)blockIdx.x >= T.block_start[ti + 1]) ++ti;
-    const int base = ((int)blockIdx.x - T.block_start[ti]) * (256 * P2P_EPT) + threadIdx.x;
-    const int n = T.numel[ti];
     const size_t goff = X.tensor_offset[ti];           // the tensor's place (floats) in the site's flat buffer
-    float bcc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    if (bias_corr) {
-#pragma unroll
-        for (int q = 0; q < 5; ++q) bcc[q] = bias_corr[q];
-    }
-    float bc1, bc2;
-    adam_bias_corrections(beta1, beta2, step, bias_corr != nullptr, bcc, bc1, bc2);
-    const float sqrt_bc2 = sqrtf(bc2);
-    const float world_f = (float)X.world;
     float gsum[P2P_EPT];
 #pragma unroll
     for (int e = 0; e < P2P_EPT; ++e) gsum[e] = 0.f;
@@ -1640,35 +1694,41 @@ __global__ __launch_bounds__(256) void k_adam_soft_p2p(const AdamTable T, const 
 #pragma unroll
         for (int e = 0; e < P2P_EPT; ++e) {
             const int i = base + e * 256;
-            part[e] = i < n ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+            // (this rank's own buffer: an ordinary load -- its backward launch is over; a peer's: system scope, served by the
+            // owner's memory, never by a cache of this GPU that could still hold last step's value of the same address)
+            part[e] = i >= n ? 0.f : (r == X.me ? src[i] : __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
         }
 #pragma unroll
         for (int e = 0; e < P2P_EPT; ++e) gsum[e] = __fadd_rn(gsum[e], part[e]);
     }
+    float bc1, bc2;
+    adam_bias_corrections(beta1, beta2, step, bias_corr != nullptr, bcc, bc1, bc2);
+    const float sqrt_bc2 = sqrtf(bc2);
+    const float world_f = (float)X.world;
 #pragma unroll
     for (int e = 0; e < P2P_EPT; ++e) {
         const int i = base + e * 256;
         if (i >= n) continue;
         const float grad = X.world > 1 ? __fdiv_rn(gsum[e], world_f) : gsum[e];
-        float p = T.p[ti][i];
+        float p = pv[e];
         const float g = fmaf(weight_decay, p, grad);
-        const float m = fmaf(beta1, T.m[ti][i], (1.f - beta1) * g);          // exp_avg.lerp_(grad, 1 - beta1)
-        const float v = fmaf(beta2, T.v[ti][i], (1.f - beta2) * g * g);
+        const float m = fmaf(beta1, mv[e], (1.f - beta1) * g);          // exp_avg.lerp_(grad, 1 - beta1)
+        const float v = fmaf(beta2, vv[e], (1.f - beta2) * g * g);
         T.m[ti][i] = m;
         T.v[ti][i] = v;
         const float denom = sqrtf(v) / sqrt_bc2 + eps;
         p -= (lr / bc1) * (m / denom);
         T.p[ti][i] = p;
         float tg = 0.f;
-        if (T.tgt[ti]) {
-            tg = T.tgt[ti][i];
+        if (has_t) {
+            tg = tv[e];
             tg = fmaf(tau, p - tg, tg);
             T.tgt[ti][i] = tg;
         }
         if (ti == 4 && (T.img_p || T.img_t)) {
             const int nn = i / H1, k = i - nn * H1;
             if (T.img_p) img_store(T.img_p, nn, k, p, true);
-            if (T.img_t && T.tgt[ti]) img_store(T.img_t, nn, k, tg, false);
+            if (T.img_t && has_t) img_store(T.img_t, nn, k, tg, false);
         }
     }
 }
@@ -2025,8 +2085,8 @@ int tt_adam_soft_update_p2p(tt_p2p *x, int site, int count, float *const *params
     if (off != (size_t)x->numel[site]) return TT_EINVAL;      // the tensors must tile the site's buffer exactly
     X.world = x->world; X.me = x->rank; X.site = site;
     for (int r = 0; r < x->world; ++r) {
-        if (!x->attached[r] || !x->block[r]) return TT_EINVAL;      // every peer's block must have been opened (tt_p2p_attach)
-        X.arrive[r] = reinterpret_cast<int *>(x->block[r]);
+        if (!x->attached[r] || !x->block[r] || !x->flags[r]) return TT_EINVAL;      // every peer's blocks must have been opened (tt_p2p_attach)
+        X.arrive[r] = reinterpret_cast<int *>(x->flags[r]);
         X.grad[r] = reinterpret_cast<const float *>(x->block[r] + x->offset[site]);
     }
     X.gave_up_host = x->gave_up_host;

@@ -246,7 +246,7 @@ class FusedLearner:
         """Data-parallel ranks WITHOUT collective launches on learn()'s chain (include/ttenv.h: tt_p2p_*): both flat gradient
         buffers move into a block of fine-grained device memory that the peers open through an IPC handle, and each rank's Adam
         launch reads every rank's gradients itself (sum in rank order / world: the same bits on every rank), behind a flag
-        barrier in device memory.  The process group -- any backend -- only carries the 64-byte handles, once.  World size 1
+        barrier in device memory.  The process group -- any backend -- only carries the handles (128 bytes per rank), once.  World size 1
         (no process group needed) runs the same launches against this rank's own block.  Call before anything is captured."""
         import os
         import torch.distributed as dist

@@ -499,9 +499,10 @@ int tt_adam_soft_update(int count, float *const *params, const float *const *gra
 /* ------------------------------------------------------------------------------------------------------
  * Peer-to-peer gradient exchange of data-parallel ranks (one process per GPU of one node): the mean over the ranks of the
  * critic's / the actor's gradient at the reference's two optimizer sites (DDPG/DDPG_agent.py:95-104) WITHOUT a collective
- * launch on learn()'s chain.  Every rank owns one block of fine-grained device memory -- per site a flat f32 gradient
- * buffer (tt_mlp_weights order: what tt_mlp_backward_weights writes when `grads` points into it) and one arrival word per
- * rank -- that its peers open through a hipIpcMemHandle; tt_adam_soft_update_p2p is tt_adam_soft_update whose gradient is
+ * launch on learn()'s chain.  Every rank owns two blocks of device memory -- per site a flat f32 gradient buffer
+ * (tt_mlp_weights order: what tt_mlp_backward_weights writes when `grads` points into it), and, in fine-grained memory, one
+ * arrival word per site and rank -- that its peers open through hipIpcMemHandles; tt_adam_soft_update_p2p is
+ * tt_adam_soft_update whose gradient is
  *      g[i] = (G_0[i] + G_1[i] + ... + G_{world-1}[i]) / world        (summed in rank order: the same bits on every rank)
  * read straight from the ranks' buffers (xGMI loads at system scope).  Hand-over, per site and learn step t = *step_dev:
  * the first workgroup of rank r's launch -- which starts only when the launch that wrote G_r (same stream) is complete and
@@ -511,11 +512,11 @@ int tt_adam_soft_update(int count, float *const *params, const float *const *gra
  * its reads of this one: two sites used in alternation (critic, actor, critic, ...) need no second barrier.  The wait is
  * bounded (tt_p2p_set_timeout, default 2 s): a launch that gives up marks a host-visible word (tt_p2p_gave_up) and goes on
  * with whatever the buffers hold -- the caller must treat the ranks as diverged.  Nothing here needs a process group; the
- * caller moves the 64-byte handles between the processes (e.g. torch.distributed.all_gather_object on any backend). */
+ * caller moves the TT_P2P_HANDLE_BYTES of tt_p2p_export between the processes (e.g. torch.distributed.all_gather_object on any backend). */
 typedef struct tt_p2p tt_p2p;
 #define TT_P2P_MAX_RANKS 8
 #define TT_P2P_MAX_SITES 4
-#define TT_P2P_HANDLE_BYTES 64
+#define TT_P2P_HANDLE_BYTES 128      /* two hipIpcMemHandle_t: the flag block, the gradient block */
 int tt_p2p_create(int device, int rank, int world, int sites, const int32_t *numel /*[sites] floats per site*/, tt_p2p **out);
 int tt_p2p_destroy(tt_p2p *x);                               /* closes the peers' blocks, frees its own (peers must be done with it) */
 int tt_p2p_export(const tt_p2p *x, void *handle_out /*[TT_P2P_HANDLE_BYTES]*/);

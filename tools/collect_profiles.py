@@ -14,7 +14,7 @@ STATS = {"ddpg": "ddpg_workload", "ddpg_serial": "ddpg_serial_order", "env": "en
 for a, b in STATS.items():
     fs = sorted(glob.glob(os.path.join(src, a, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getsize)
     if fs:
-        shutil.copy(fs[-1], f"{dst}_{b}_kernel_stats.csv")       # (the child of bench.py --gpus 1 holds the kernels)
+        shutil.copy(fs[-1], f"{dst}_{b}_kernel_stats.csv")       # (the largest file: the process that ran the kernels)
 for a, b in (("ddpg_step_timeline.txt", "ddpg_step_timeline.txt"), ("ddpg_serial_step_timeline.txt", "ddpg_serial_order_step_timeline.txt"),
              ("learn_blocks.txt", "learn_workgroup_stamps.txt"), ("pmc4m_summary.json", "pmc_k_step_4m_envs.json")):
     f = os.path.join(src, a)
