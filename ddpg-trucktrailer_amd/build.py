@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", f) for f in ("ttenv.hip", "ttnet.hip", "ttnet_split.hip", "ttlearn.hip", "ttp2p.hip")]
-HDR = [os.path.join(ROOT, "include", "ttenv.h"), os.path.join(HERE, "csrc", "ttnet_common.h"), os.path.join(HERE, "csrc", "ttnet_pack.h"), os.path.join(HERE, "csrc", "ttp2p.h")]
+HDR = [os.path.join(ROOT, "include", "ttenv.h"), os.path.join(HERE, "csrc", "ttnet_common.h"), os.path.join(HERE, "csrc", "ttnet_pack.h"), os.path.join(HERE, "csrc", "ttp2p.h"), os.path.join(HERE, "csrc", "ttstamps.h")]
 LIB = os.path.join(HERE, "libttenv.so")
 
 

@@ -646,6 +646,11 @@ __device__ __forceinline__ void write_info(const Info &info, size_t N, int i, co
 // ------------------------------------------------------------------------------------------
 // the vector step.  RANDOM_POLICY: the action is drawn in-kernel (BASELINE.json config 2), keyed by
 // (policy seed, env, step-in-episode, episode number) so that a captured hipGraph replays correctly.
+#ifdef TT_STAMPS
+#include "ttstamps.h"
+__device__ unsigned long long g_stepblk[1024][2];
+__device__ TTLog g_log_step;
+#endif
 template <bool PER_ENV, bool INFO, bool AUTO_RESET, bool RANDOM_POLICY>
 __global__ __launch_bounds__(BLOCK) void k_step(const KParams P, const int n, const Bufs b,
                                                 const float *__restrict__ action, float *__restrict__ action_out,
@@ -653,6 +658,9 @@ __global__ __launch_bounds__(BLOCK) void k_step(const KParams P, const int n, co
                                                 uint8_t *__restrict__ done, const Info info, const uint64_t seed,
                                                 const uint64_t policy_seed, const int *__restrict__ cursor) {
     __shared__ __attribute__((aligned(16))) float tile[BLOCK * OBS];
+#ifdef TT_STAMPS      // diagnostic build: wall clock (100 MHz) at the begin and end of every workgroup (tools/step_timeline.py)
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_stepblk[blockIdx.x][0] = wall_clock64();
+#endif
     if (cursor) {       // ring addressing (tt_env_step_ring): obs / reward / done are the ring's bases, the slots come from the cursor
         obs += (size_t)cursor[1] * n * OBS;
         reward += (size_t)cursor[0] * n;
@@ -707,6 +715,14 @@ __global__ __launch_bounds__(BLOCK) void k_step(const KParams P, const int n, co
         store_env(b, i, e);
     }
     store_obs_tile(tile, of, valid, obs, block_first, nv, P.nt != 0);
+#ifdef TT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        g_stepblk[blockIdx.x][1] = wall_clock64();
+        tt_log_add(g_log_step, g_stepblk[blockIdx.x][0], g_stepblk[blockIdx.x][1]);
+    }
+#endif
 }
 
 // K vector steps in ONE launch with the random policy: the env stays in registers, only the last
@@ -1045,6 +1061,16 @@ int step_common(tt_env *env, const float *action, float *action_out, float *obs,
 extern "C" {
 
 int tt_version(void) { return TT_VERSION; }
+#ifdef TT_STAMPS
+int tt_debug_log_step(unsigned long long *out, int reset) {      // out: 1 + 2 * TT_LOG_CAP words (count, then begin / end pairs) or NULL
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_log_step), sizeof(TTLog)) != hipSuccess) return -3;
+    if (reset) { const unsigned long long z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_log_step), &z, sizeof(z)) != hipSuccess) return -3; }
+    return 0;
+}
+int tt_debug_step_blocks(unsigned long long *out2048) {
+    return hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_stepblk), sizeof(unsigned long long) * 2048) == hipSuccess ? 0 : -3;
+}
+#endif
 
 const char *tt_last_error(const tt_env *env) { return env ? env->err : g_err; }
 

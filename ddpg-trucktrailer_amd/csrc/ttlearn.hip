@@ -22,7 +22,8 @@
 #include "ttenv.h"
 #include "ttnet_common.h"      // the replay draw (ring_sample_index): k_fwd_multi can make it itself
 #include "ttnet_pack.h"        // the policy image (split_pack_body): k_bwd_rows_pair can carry its pack
-#include "ttp2p.h"             // the peer-to-peer gradient exchange of data-parallel ranks: k_adam_soft_p2p reads it
+#include "ttp2p.h"
+#include "ttstamps.h"             // the peer-to-peer gradient exchange of data-parallel ranks: k_adam_soft_p2p reads it
 
 namespace {
 
@@ -95,7 +96,9 @@ __device__ unsigned long long g_wst[2][16];     // phase stamps of workgroup 0 o
 // begin / end of every workgroup of learn()'s launches: [kernel][block][2] (tools/learn_blocks.py)
 __device__ unsigned long long g_kblk[6][512][2];
 #define KBEGIN(k) do { if (threadIdx.x == 0 && blockIdx.x < 512) g_kblk[k][blockIdx.x][0] = wall_clock64(); } while (0)
-#define KEND(k) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 512) g_kblk[k][blockIdx.x][1] = wall_clock64(); } while (0)
+__device__ TTLog g_log_learn[5];
+#define KEND(k) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 512) { g_kblk[k][blockIdx.x][1] = wall_clock64();       \
+        if ((k) < 5) tt_log_add(g_log_learn[(k) < 5 ? (k) : 0], g_kblk[k][blockIdx.x][0], g_kblk[k][blockIdx.x][1]); } } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #define STAMPB(i, blk0) do { } while (0)
@@ -2114,6 +2117,15 @@ int tt_debug_wst(unsigned long long *out32) {
 }
 int tt_debug_kblocks(unsigned long long *out6x1024) {
     return hipMemcpyFromSymbol(out6x1024, HIP_SYMBOL(g_kblk), sizeof(unsigned long long) * 6 * 1024) == hipSuccess ? 0 : -3;
+}
+int tt_debug_log_learn(int k, unsigned long long *out, int reset) {
+    if (k < 0 || k >= 5) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_log_learn), sizeof(TTLog), sizeof(TTLog) * (size_t)k) != hipSuccess) return -3;
+    if (reset) { const unsigned long long z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_log_learn), &z, sizeof(z), sizeof(TTLog) * (size_t)k) != hipSuccess) return -3; }
+    return 0;
+}
+int tt_debug_learn_poll(unsigned long long *out4) {
+    return hipMemcpyFromSymbol(out4, HIP_SYMBOL(ttnet::g_poll), sizeof(unsigned long long) * 4) == hipSuccess ? 0 : -3;
 }
 int tt_debug_stamps(unsigned long long *out32) {
     return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -3;

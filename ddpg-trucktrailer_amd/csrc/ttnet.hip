@@ -289,6 +289,9 @@ extern "C" {
 #ifdef TT_STAMPS
 int tt_debug_nstamps(unsigned long long *out16) { return ttnet::split_debug_stamps(out16); }
 int tt_debug_bstamps(unsigned long long *out, int nblocks) { return ttnet::split_debug_block_stamps(out, nblocks); }
+int tt_debug_policy_tiles(unsigned long long *out4096) { return ttnet::split_debug_tiles(out4096); }
+int tt_debug_policy_poll(unsigned long long *out4) { return ttnet::split_debug_poll(out4); }
+int tt_debug_log_policy(unsigned long long *out, int reset) { return ttnet::split_debug_log(out, reset); }
 #endif
 
 uint64_t tt_mlp_split_ws_bytes(void) { return (uint64_t)split_ws_bytes(); }

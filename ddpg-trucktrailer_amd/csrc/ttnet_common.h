@@ -98,6 +98,30 @@ __device__ __forceinline__ void finish_row(const int row, const float v, float *
     }
 }
 
+// finish_row in two pieces, for a kernel that can ask for the row's noise inputs long before the head's output exists (the split
+// kernel, per tile): everything of the OU update -- the state, the done flag of the previous step, Philox, Box-Muller -- is
+// independent of the network.  ou_advance() is noise.py:13-17 + trajectory restart (trainv2.py:492) on values loaded earlier;
+// finish_row_noise() is what is left once v is known: tanh, the sum, three stores.  Same arithmetic, same bits as finish_row.
+__device__ __forceinline__ float ou_advance(const int row, const float x_prev, const bool restart, const ActArgs &act,
+                                            const unsigned long long st) {
+    float x = restart ? 0.f : x_prev;
+    uint32_t rnd[4];
+    philox4x32((uint32_t)row, (uint32_t)st, (uint32_t)(st >> 32), 0x0A5Eu, (uint32_t)act.seed, (uint32_t)(act.seed >> 32), rnd);
+    const float u1 = ((float)(rnd[0] >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float u2 = ((float)(rnd[1] >> 8) + 0.5f) * (1.f / 16777216.f);
+    const float nrm = sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    return fmaf(x, act.decay, act.scale * nrm);
+}
+__device__ __forceinline__ void finish_row_noise(const int row, const float v, float *__restrict__ out, const ActArgs &act,
+                                                 const float x_new, float *__restrict__ act_raw) {
+    const float mu = tanhf(v);
+    if (out) out[row] = mu;
+    act.ou[row] = x_new;
+    const float a = mu + x_new;
+    act_raw[row] = a;
+    act.act_scaled[row] = fminf(fmaxf(a, -1.f), 1.f) * act.high;
+}
+
 
 // ------------------------------------------------------------------------------------------------------
 // Uniform sampling WITH replacement from the trajectory ring (replay_buffer.py:23-34 draws np.random.choice(max_mem,
@@ -239,6 +263,14 @@ __device__ __forceinline__ void write_cursor(const RingCursor &c) {
 // epoch (relaxed, agent scope, s_sleep between polls, bounded), then agent-scope acquire, wait, workgroup barrier; only then
 // does the workgroup read cursor or image.  Both sides run on every ring-addressed launch; where the two launches are ordered
 // anyway (same stream) the first poll succeeds.
+#ifdef TT_STAMPS      // diagnostic build: how the two hand-over waits ended, per workgroup -- [0] image: first poll succeeded, [1] image:
+// had to wait, [2] progress: first poll, [3] progress: waited (one copy per translation unit: the policy's in ttnet_split.hip,
+// learn()'s in ttlearn.hip)
+static __device__ unsigned long long g_poll[4];
+#define TT_POLL(i) atomicAdd(&g_poll[i], 1ull)
+#else
+#define TT_POLL(i) do { } while (0)
+#endif
 constexpr int CUR_EPOCH = 12, CUR_ARRIVED = 14, CUR_GAVE_UP = 15, CUR_PROGRESS = 16, CUR_GAVE_UP_MIRROR = 18;
 constexpr unsigned long long TT_IMAGE_WAIT_TICKS = 25000000ull;      // 0.25 s
 // (Tried: write-through sc1 stores of image and cursor + each wave's wait, no release fence -- cheaper for the pack launch, but
@@ -266,7 +298,18 @@ __device__ __forceinline__ void publish_image(const RingCursor &c, const int wor
         }
     }
 }
-__device__ __forceinline__ void await_image(int *cursor, const long long *step_dev) {             // every thread of the block
+// early: both epoch words as thread 0 found them BEFORE it knew the step number (await_image_early: loads that do not depend on
+// the step counter, so that they share its round trip instead of following it); {0, 0} from the other threads / without a cursor
+struct EpochPair { int e[2]; };
+__device__ __forceinline__ EpochPair await_image_early(int *cursor) {
+    EpochPair p{{0, 0}};
+    if (cursor && threadIdx.x == 0) {
+        p.e[0] = __hip_atomic_load(cursor + CUR_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p.e[1] = __hip_atomic_load(cursor + CUR_EPOCH + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return p;
+}
+__device__ __forceinline__ void await_image(int *cursor, const long long *step_dev, const EpochPair early = EpochPair{{0, 0}}) {             // every thread of the block
     if (!cursor) return;
     if (threadIdx.x == 0) {
         const long long k = *step_dev;
@@ -281,7 +324,11 @@ __device__ __forceinline__ void await_image(int *cursor, const long long *step_d
         // word orders that).  So also a workgroup that starts late and finds an epoch that was published in the middle of this
         // dispatch meets no line of the image that was cached before the publish.  The pack launch of step k + 2 is the next
         // writer.  Checked by the 1500-step bitwise test and the soaks (tools/soak.py), not provable from here.
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+        // (`early`: the same word as read a round trip earlier, beside the step counter; epochs only grow, so an early value that
+        // is large enough is as good as a fresh one)
+        if (early.e[k & 1] - want >= 0 || __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want >= 0) TT_POLL(0);
+        else {
+            TT_POLL(1);
             // (one poll per ~3 us and workgroup: 171 workgroups polling one word every 0.1 us slowed the very launches they
             // were waiting for -- seen under rocprofv3's kernel trace, where the learn chain falls behind: 224 us per policy launch)
             const unsigned long long t0 = wall_clock64();
@@ -309,7 +356,9 @@ __device__ __forceinline__ void await_progress(int *progress, const long long *k
     if (!progress) return;
     if (threadIdx.x == 0) {
         const int want = (int)*k_dev;
-        if (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+        if (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want >= 0) TT_POLL(2);
+        else {
+            TT_POLL(3);
             const unsigned long long t0 = wall_clock64();
             while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
                 __builtin_amdgcn_s_sleep(32);
@@ -337,6 +386,9 @@ int split_forward(bool critic, int n, const float *obs, const float *action, con
                   const ActArgs &act, hipStream_t stream);
 #ifdef TT_STAMPS
 int split_debug_stamps(unsigned long long *out16);
+int split_debug_tiles(unsigned long long *out4096);
+int split_debug_poll(unsigned long long *out4);
+int split_debug_log(unsigned long long *out, int reset);
 int split_debug_block_stamps(unsigned long long *out, int nblocks);
 #endif
 

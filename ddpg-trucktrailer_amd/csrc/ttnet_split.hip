@@ -29,6 +29,7 @@
 //   fc1 fragments, also brought into LDS by DMA.
 #include "ttnet_common.h"
 #include "ttnet_pack.h"
+#include "ttstamps.h"
 
 namespace ttnet {
 namespace {
@@ -40,8 +41,13 @@ __device__ unsigned long long g_bstamps[4096 * 8];      // [block][phase] wall c
         if (blockIdx.x < 4096) { g_bstamps[blockIdx.x * 8 + (i)] = w_;                                                      \
             if ((i) == 0) g_bstamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)); }     \
         if (blockIdx.x == 0) { g_nstamps[i] = w_; g_nstamps[8 + i] = clock64(); } } } while (0)
+// begin / end of every tile a workgroup takes: [block][round of the tile loop][2] (tools/step_timeline.py)
+__device__ unsigned long long g_tile[512][4][2];
+__device__ TTLog g_log_tile;
+#define TSTAMP(round, e) do { if (threadIdx.x == 0 && blockIdx.x < 512 && (round) < 4) g_tile[blockIdx.x][round][e] = wall_clock64(); } while (0)
 #else
 #define NSTAMP(i) do { } while (0)
+#define TSTAMP(round, e) do { } while (0)
 #endif
 
 __global__ __launch_bounds__(256) void k_split_pack(const Weights W, const bool critic, unsigned char *__restrict__ ws,
@@ -115,6 +121,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     // (that of the step's parity: the other one may be being written for the next step) comes from the opening pack launch,
     // which need not be ordered before this launch: await_image (ttnet_common.h) -- behind the first tile's observation loads,
     // which do not depend on it.
+    const EpochPair epochs = await_image_early(act.cursor);      // (requested beside the step counter, not behind it)
     const long long kstep = act.cursor ? *act.step_dev : 0;
     const bool odd = act.cursor && (kstep & 1);
     const bool local = act.cursor && act.ring_slots > 0;
@@ -149,9 +156,18 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     // unconditional loads from clamped (always valid) addresses, selected afterwards: 16 loads in flight at once
     // instead of 16 exec-masked round trips
     float xo[S1][8];                                                          // obs^T as the B operand: input 16 s + 8 h + j
+    // choose_action's noise inputs of the tile's rows -- the OU state and the previous step's done flag (DDPG_agent.py:36-49,
+    // noise.py:13-17, trainv2.py:492) -- are requested WITH the observations: read where the head's output is known (finish_row)
+    // they were two dependent round trips to memory at the very end of every tile, with nothing left to hide them behind
+    float ou_pre = 0.f;
+    unsigned dp_pre = 0u;
+    const bool with_noise = !CRITIC && act.ou != nullptr;                     // (uniform over the launch)
+    const uint8_t *dprev = act.done_prev;                                    // the done flags that restart a row's noise, or nullptr
+    float *araw = act.act_raw;
     auto load_obs = [&](const int tile) __attribute__((always_inline)) {
         const int row = tile * ROWS + wave * WROWS + r;
-        const float *orow = obs_base + (size_t)(row < n ? row : n - 1) * IN;
+        const int rowc = row < n ? row : n - 1;
+        const float *orow = obs_base + (size_t)rowc * IN;
 #pragma unroll
         for (int s = 0; s < S1; ++s)
 #pragma unroll
@@ -159,6 +175,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
                 const int k = 16 * s + 8 * h + j;
                 xo[s][j] = orow[k < IN ? k : IN - 1];
             }
+        if (with_noise) {
+            ou_pre = act.ou[rowc];
+            dp_pre = dprev ? (unsigned)dprev[rowc] : 0u;
+        }
     };
 
     NSTAMP(0);
@@ -166,13 +186,22 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     // its own count), then packed fc1 + the per-neuron vectors, then k16 steps 0 and 1 of fc2 by DMA
     int tile = tile0 + (int)blockIdx.x;
     if (tile >= tile_end) return;
+    if (local) {                          // the ring's slots of this step follow from the step counter: no look at the cursor
+        const int sl = act.ring_slots;
+        dprev = kstep > 0 ? act.done_prev + (size_t)((kstep + sl - 1) % sl) * act.ring_n : nullptr;
+        araw = act.act_raw + (size_t)slot_t * act.ring_n;
+    }
     if (!act.cursor || local) load_obs(tile);
-    await_image(act.cursor, act.step_dev);
+    await_image(act.cursor, act.step_dev, epochs);
     const unsigned char *wsl = (odd && ws_alt) ? ws_alt : ws;
     if (act.cursor && !local) {          // (a caller that gave no slot count: the cursor the pack launch wrote)
         obs_base = resolve_obs(act, obs);
+        const int *c = cursor_of(act);
+        dprev = c[3] ? act.done_prev + (size_t)c[2] * act.ring_n : nullptr;
+        araw = act.act_raw + (size_t)c[0] * act.ring_n;
         load_obs(tile);
     }
+    const unsigned long long noise_step = act.step + (act.step_dev ? (unsigned long long)*act.step_dev : 0ull);
     if (act.cursor && tile0 == 0 && blockIdx.x == 0 && tid == 0)      // this launch has begun: the step chain is at step kstep
         __hip_atomic_store(act.cursor + CUR_PROGRESS, (int)(kstep + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (act.cursor && tile0 == 0 && blockIdx.x == 0 && tid < 4) {
@@ -187,6 +216,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
 #pragma unroll
     for (int i = 0; i < 10; ++i) issue_step_piece(wsl, ldsw_w2_0, i / 5, i % 5);
     bool first = true;
+#ifdef TT_STAMPS
+    int round = 0;
+    if (threadIdx.x == 0 && blockIdx.x < 512) for (int q = 0; q < 4; ++q) g_tile[blockIdx.x][q][0] = g_tile[blockIdx.x][q][1] = 0ull;
+    if (threadIdx.x == 0 && blockIdx.x < 512) g_tile[blockIdx.x][0][0] = wall_clock64();
+#endif
 
 #pragma unroll 1
     for (;;) {
@@ -205,6 +239,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
                 const int k = 16 * s + 8 * h + j;
                 xo[s][j] = k < IN ? (row < n ? xo[s][j] : 0.f) : (k == IN ? 1.f : 0.f);
             }
+        // this row's noise for the step (independent of the network: see load_obs), from the values requested a tile ago
+        float ou_next = 0.f;
+        if (with_noise) ou_next = ou_advance(row < n ? row : n - 1, ou_pre, dp_pre != 0u, act, noise_step);
         uint4 xb[S1][2];                                                      // the observation's h and m pieces
 #pragma unroll
         for (int s = 0; s < S1; ++s) {
@@ -458,8 +495,17 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
         }
         const float dot = dotp[0] + dotp[1];
         const float v = dot + __shfl_xor(dot, 32) + lds4(pv1 - 4 * h + VEC_FLOATS).x;
-        if (h == 0 && row < n) finish_row<CRITIC>(row, v, out, act);
+        if (h == 0 && row < n) {
+            if (with_noise) finish_row_noise(row, v, out, act, ou_next, araw);
+            else finish_row<CRITIC>(row, v, out, act);
+        }
         if (first) NSTAMP(5);
+#ifdef TT_STAMPS
+        TSTAMP(round, 1);
+        if (threadIdx.x == 0 && blockIdx.x < 512 && round < 4) tt_log_add(g_log_tile, g_tile[blockIdx.x][round][0], g_tile[blockIdx.x][round][1]);
+        ++round;
+        if (more_tiles) TSTAMP(round, 0);
+#endif
         if (!more_tiles) break;
         tile = next;
         first = false;
@@ -471,6 +517,17 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
 #ifdef TT_STAMPS
 int split_debug_stamps(unsigned long long *out16) {
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_nstamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -3;
+}
+int split_debug_tiles(unsigned long long *out4096) {
+    return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(g_tile), sizeof(unsigned long long) * 512 * 4 * 2) == hipSuccess ? 0 : -3;
+}
+int split_debug_log(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_log_tile), sizeof(TTLog)) != hipSuccess) return -3;
+    if (reset) { const unsigned long long z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_log_tile), &z, sizeof(z)) != hipSuccess) return -3; }
+    return 0;
+}
+int split_debug_poll(unsigned long long *out4) {
+    return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_poll), sizeof(unsigned long long) * 4) == hipSuccess ? 0 : -3;
 }
 int split_debug_block_stamps(unsigned long long *out, int nblocks) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bstamps), sizeof(unsigned long long) * 8 * (nblocks < 4096 ? nblocks : 4096)) == hipSuccess ? 0 : -3;
