@@ -107,6 +107,37 @@ __device__ TTLog g_log_learn[5];
 #define WST(i) do { } while (0)
 #endif
 
+// Kernel arguments of these launches are structs of a few hundred bytes to over a kilobyte (k_fwd_multi: four jobs of thirteen
+// weight pointers each + the replay draw).  The compiler reads them from the kernarg segment lazily, field group by field group,
+// each group with its own `s_waitcnt lgkmcnt(0)` -- and every first touch of a 64-byte line misses the scalar cache: a row kernel
+// had three to five such round trips spread over its critical path.  kernarg_warm<BYTES>() touches every line of the first BYTES of
+// the segment at the top of the kernel, all loads in flight together, one wait: the later reads hit.
+template <int OFF>
+__device__ __forceinline__ unsigned kernarg_touch_line(const void *ka) {
+    unsigned r;
+    asm volatile("s_load_dword %0, %1, %2" : "=s"(r) : "s"(ka), "i"(OFF));
+    return r;
+}
+template <int LINE, int LINES>
+__device__ __forceinline__ void kernarg_touch_all(const void *ka, unsigned (&t)[LINES]) {
+    if constexpr (LINE < LINES) {
+        t[LINE] = kernarg_touch_line<LINE * 64>(ka);
+        kernarg_touch_all<LINE + 1, LINES>(ka, t);
+    }
+}
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+#ifndef TT_DBG_NO_KERNARG_WARM
+    constexpr int LINES = (BYTES + 63) / 64;
+    const void *ka = (const void *)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned t[LINES];
+    kernarg_touch_all<0, LINES>(ka, t);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < LINES; ++i) asm volatile("" ::"s"(t[i]));      // (the destinations stay allocated until the loads are back)
+#endif
+}
+
 // __restrict__ on the members: none of these buffers alias, and without it every store (saved activations,
 // gradients) pins the loads that follow it in program order
 struct Weights {
@@ -597,6 +628,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_small(const int n, const float 
     __shared__ __attribute__((aligned(16))) float h1_s[H1S_FLOATS];
     __shared__ __attribute__((aligned(16))) float z_s[TR * DS];
     __shared__ __attribute__((aligned(16))) float w1_s[H1 * IN];
+    kernarg_warm<8 + 16 + (int)sizeof(Weights) + 8 + (int)sizeof(Saved) + 16>();
     KBEGIN(3);
     fwd_small_body<CRITIC>(n, obs, action, W, out, sv, dq_da, z_state, h1_s, z_s, w1_s, blockIdx.x * TR);
     KEND(3);
@@ -629,6 +661,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_multi(const FwdJobs J) {
     __shared__ __attribute__((aligned(16))) float h1_s[H1S_FLOATS];
     __shared__ __attribute__((aligned(16))) float z_s[TR * DS];
     __shared__ __attribute__((aligned(16))) float w1_s[H1 * IN];
+    kernarg_warm<(int)sizeof(FwdJobs)>();
     const int job = blockIdx.x / J.blocks_per_job, row0 = (blockIdx.x - job * J.blocks_per_job) * TR;
     const FwdJob &q = J.j[job];
     KBEGIN(0);
@@ -1079,6 +1112,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_rows_pair(const int n, const fl
     __shared__ __attribute__((aligned(16))) float dx2_s[DXS_FLOATS];
     __shared__ float red[2 * NW * TR];
     __shared__ float rsc_s[TR];
+    kernarg_warm<16 + 2 * ((int)sizeof(Weights) + (int)sizeof(Saved) + (int)sizeof(BwdOut)) + (int)sizeof(TdIn) + 8>();
     const int nb = (n + TR - 1) / TR;
     if ((int)blockIdx.x == 2 * nb) {         // the extra workgroup: counters + bias corrections (nothing in this launch reads them)
         if (threadIdx.x == 0) clock_tick(td);
@@ -1223,6 +1257,7 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
     auto row_factor = [&](const int b) -> float { return ROWSCALE ? f_s[b] : 1.f; };
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
     const int blk = blockIdx.x;
+    kernarg_warm<24 + (int)sizeof(Saved) + (int)sizeof(BwdOut) + (int)sizeof(Grads) + (int)sizeof(AdamFused) + (int)sizeof(RowScale)>();
     KBEGIN(ROWSCALE ? 4 : 2);
     STAMPB(12, 0); STAMPB(14, NU2); STAMPB(5, NU2 + NU1);
 #ifdef TT_STAMPS

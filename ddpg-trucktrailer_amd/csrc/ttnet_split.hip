@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     if (tile >= tile_end) return;
     if (local) {                          // the ring's slots of this step follow from the step counter: no look at the cursor
         const int sl = act.ring_slots;
-        dprev = kstep > 0 ? act.done_prev + (size_t)((kstep + sl - 1) % sl) * act.ring_n : nullptr;
+        const int slot_prev = slot_t == 0 ? sl - 1 : slot_t - 1;          // (one 64-bit modulo per launch, not three)
+        dprev = kstep > 0 ? act.done_prev + (size_t)slot_prev * act.ring_n : nullptr;
         araw = act.act_raw + (size_t)slot_t * act.ring_n;
     }
     if (!act.cursor || local) load_obs(tile);
@@ -207,7 +208,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     if (act.cursor && tile0 == 0 && blockIdx.x == 0 && tid < 4) {
         const int sl = act.ring_slots;
         act.cursor[tid] = !local ? cursor_of(act)[tid]
-                                 : (tid == 0 ? slot_t : tid == 1 ? (int)((kstep + 1) % sl) : tid == 2 ? (int)((kstep + sl - 1) % sl) : (kstep > 0 ? 1 : 0));
+                                 : (tid == 0 ? slot_t : tid == 1 ? (slot_t + 1 == sl ? 0 : slot_t + 1)
+                                                      : tid == 2 ? (slot_t == 0 ? sl - 1 : slot_t - 1) : (kstep > 0 ? 1 : 0));
     }
     issue_fc1(wsl, ldsw_w1_0);
 #pragma unroll
