@@ -337,21 +337,31 @@ def main():
     nccl = os.environ.get("TT_DIST_BACKEND", "nccl") == "nccl"
     dp_vote, dp_asked = False, "n/a"
     p2p = args.dp_mode == "p2p" and args.workload == "ddpg"
+    p2p_vote = p2p
     if p2p:
         dp_vote, dp_asked = True, "--dp-mode p2p"
-    elif world > 1 and args.workload == "ddpg" and nccl:
-        # one hipGraph per data-parallel step if this node replays a captured RCCL all-reduce correctly: asked in
-        # throw-away child processes before this rank touches its GPU (ddpg-trucktrailer_amd/dp_probe.py).  The answer
-        # here is this rank's VOTE; the ranks agree on one structure below, once the process group exists.
-        if args.dp_mode == "auto" and "TT_DP_GRAPH_COLLECTIVES" in os.environ:
-            dp_vote, dp_asked = os.environ["TT_DP_GRAPH_COLLECTIVES"] == "1", "TT_DP_GRAPH_COLLECTIVES"
-        elif args.dp_mode == "auto":
-            from ddpg_trucktrailer_amd.dp_probe import graph_collectives_ok, probe_port
-            limit = min(240.0, max(30.0, args.watchdog_seconds - 60.0))
-            wd.enter("dp-probe", limit + 60.0)
-            dp_vote, dp_asked = graph_collectives_ok(timeout=limit, port=probe_port()), "probe"
-        else:
-            dp_vote, dp_asked = args.dp_mode == "graph", "--dp-mode " + args.dp_mode
+    elif world > 1 and args.workload == "ddpg":
+        # N > 1: which structure a data-parallel vector step gets is asked in throw-away child processes BEFORE this rank touches
+        # its GPU (ddpg-trucktrailer_amd/dp_probe.py), and the answers here are this rank's VOTES; the ranks agree below, once
+        # the process group exists.  auto: (1) the peer-to-peer exchange if every rank's probe ran it correctly across the real
+        # ranks (no collective on learn()'s chain at all), else (2) one hipGraph per step with the two RCCL all-reduces as its
+        # nodes if this node replays a captured all-reduce correctly, else (3) three graph segments with eager all-reduces.
+        limit = min(240.0, max(30.0, args.watchdog_seconds - 60.0))
+        if args.dp_mode == "auto" and os.environ.get("TT_DP_AUTO_P2P", "1") == "1":
+            from ddpg_trucktrailer_amd.dp_probe import p2p_exchange_ok, probe_port
+            wd.enter("dp-probe (p2p exchange)", limit + 60.0)
+            p2p_vote = p2p_exchange_ok(timeout=min(limit, 180.0), port=probe_port(tag="p2p"))
+            dp_asked = "probe (p2p exchange)"
+        if nccl and not p2p_vote:         # (a rank whose exchange probe passed does not ask about captured collectives as well: if the
+            #                               others' did not, the run falls back to segments -- the slowest structure, the safest)
+            if args.dp_mode == "auto" and "TT_DP_GRAPH_COLLECTIVES" in os.environ:
+                dp_vote, dp_asked = os.environ["TT_DP_GRAPH_COLLECTIVES"] == "1", "TT_DP_GRAPH_COLLECTIVES"
+            elif args.dp_mode == "auto":
+                from ddpg_trucktrailer_amd.dp_probe import graph_collectives_ok, probe_port
+                wd.enter("dp-probe", limit + 60.0)
+                dp_vote, dp_asked = graph_collectives_ok(timeout=limit, port=probe_port()), "probe"
+            else:
+                dp_vote, dp_asked = args.dp_mode == "graph", "--dp-mode " + args.dp_mode
 
     wd.enter("init")
     import torch
@@ -373,6 +383,8 @@ def main():
         else:
             dist.init_process_group(backend)
         from ddpg_trucktrailer_amd.dp_probe import agree
+        if not p2p and agree(p2p_vote, dev):   # every rank's probe ran the exchange correctly: it is the structure of this run
+            p2p = True
         dp_graph = agree(dp_vote, dev)         # every rank builds the same launch structure
     else:
         dp_graph = False
@@ -449,7 +461,7 @@ def main():
         extra = {"batch": args.batch, "updates_per_step": args.updates_per_step,
                  "replay_capacity": args.replay_slots * n, "launch": launch, "order": order,
                  "dp_mode": (None if not loop.dp else
-                             {"asked": args.dp_mode, "decided_by": dp_asked, "this_rank_vote": bool(dp_vote),
+                             {"asked": args.dp_mode, "decided_by": dp_asked, "this_rank_vote": bool(p2p_vote if p2p else dp_vote),
                               "agreed_by_all_ranks": "p2p" if p2p else ("graph" if loop.dp_single_graph else "segments")}),
                  "env_steps_per_update": n / args.updates_per_step, "setup_vector_steps": loop.vector_steps,
                  "note": ("throughput of the configuration BASELINE.json names; how the same loop trains at this and at other "

@@ -458,6 +458,54 @@ def test_p2p_wait_is_bounded_and_a_give_up_is_an_error(gpu_device):
     assert took < 200
 
 
+@pytest.mark.gpu
+def test_bench_two_ranks_p2p_rehearsal_on_one_gpu(gpu_device):
+    """bench.py's own N > 1 path end to end with the peer-to-peer exchange: `python bench.py --gpus 2 --dp-mode p2p` starts its two
+    ranks itself (TT_DIST_BACKEND=gloo lets them share the ONE GPU of the test box: the numbers mean nothing, the path does), the
+    ranks open each other's exchange blocks, every vector step is one hipGraph, rank 0 prints ONE line that says which structure
+    ran, and no wait was abandoned."""
+    import json
+    import subprocess
+    env = dict(os.environ, TT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", TT_P2P_TIMEOUT_S="30")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dp-mode", "p2p", "--n-envs", "4096", "--steps", "40",
+                        "--warmup", "8", "--repeats", "1", "--watchdog-seconds", "240"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["n_envs_total"] == 8192 and d["scaling"] == "weak"
+    assert d["config"]["dp_mode"]["agreed_by_all_ranks"] == "p2p" and "no collective" in d["config"]["launch"]
+    assert d["value"] == pytest.approx(8192 * 40 / (d["ms_per_step"] * 1e-3 * 40), rel=1e-9)
+    assert "allreduce_us" in d
+
+
+@pytest.mark.gpu
+def test_p2p_exchange_probe_and_auto_mode_on_one_gpu(gpu_device):
+    """dp_probe.p2p_exchange_ok(): one throw-away child per rank opens the peers' exchange blocks, runs the exchange's launch for both
+    sites eagerly and from a replayed hipGraph, and checks mean + identical bits across the ranks -- two ranks on the ONE GPU here;
+    and `bench.py --gpus 2` with --dp-mode auto takes the exchange when every rank's probe said yes (TT_DIST_BACKEND=gloo: the ranks
+    share the GPU), and says in its line who decided."""
+    import json
+    import subprocess
+    port = _free_port()
+    code = ("import sys; sys.path.insert(0, %r); from ddpg_trucktrailer_amd.dp_probe import p2p_exchange_ok; "
+            "print('answer', p2p_exchange_ok(150.0))" % ROOT)
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", TT_DP_PROBE_PORT=str(port),
+                                       MASTER_PORT=str(port), TT_DP_PROBE_VERBOSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all("answer True" in o for o in outs), outs
+    env = dict(os.environ, TT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", TT_P2P_TIMEOUT_S="30")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n-envs", "4096", "--steps", "20", "--warmup", "5",
+                        "--repeats", "0", "--watchdog-seconds", "280"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["dp_mode"] == {"asked": "auto", "decided_by": "probe (p2p exchange)", "this_rank_vote": True,
+                                                           "agreed_by_all_ranks": "p2p"}
+
+
 def test_bench_refuses_fewer_gpus_than_ranks():
     """`python bench.py --gpus N` starts N ranks itself; with fewer than N GPUs visible it prints no line and exits 2."""
     import subprocess
