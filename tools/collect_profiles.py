@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Copy what a tools/profile_round3.sh run left under gpurun_out/<tag> into profiles/<prefix>_* (the files the documents cite).
-usage: collect_profiles.py gpurun_out/<tag> profiles/r03"""
+"""Copy what a tools/profile_round4.sh run left under gpurun_out/<tag> into profiles/<prefix>_* (the files the documents cite).
+usage: collect_profiles.py gpurun_out/<tag> profiles/r04"""
 import glob, os, shutil, subprocess, sys
 src, dst = sys.argv[1], sys.argv[2]
 BENCH = {"default": "default", "driver_form": "driver_form_20_5", "env": "env_workload", "graph_edge": "graph_edge", "n4096": "n4096",

@@ -24,4 +24,23 @@ TT_LIB_PATH=$STAMPS timeout -k 10 300 python3 tools/learn_blocks.py > $out/learn
 TT_LIB_PATH=$STAMPS timeout -k 10 300 python3 tools/step_timeline.py > $out/step_timeline.txt 2>&1 || echo "step_timeline failed"
 python3 tools/time_actor_cap.py > $out/time_actor_cap.txt 2>&1
 timeout -k 10 400 python3 tools/soak.py 65536 200000 > $out/soak.txt 2>&1 || echo "soak failed"
+if [ "${PMC4M:-0}" = "1" ]; then      # what bounds k_step at N = 4 M envs (round 3's study: kernel trace + SQ / TCC / FETCH / WRITE passes, each its own run)
+rocprofv3 -L > $out/counters.txt 2>&1
+SQ1=$(python3 tools/pmc_pick.py $out/counters.txt 8 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU)
+SQ2=$(python3 tools/pmc_pick.py $out/counters.txt 8 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS)
+T1=$(python3 tools/pmc_pick.py $out/counters.txt 4 TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_RDREQ_DRAM_sum)
+T2=$(python3 tools/pmc_pick.py $out/counters.txt 4 TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum TCC_EA0_WRREQ_DRAM_sum)
+echo "SQ1=$SQ1 | SQ2=$SQ2 | T1=$T1 | T2=$T2" > $out/pmc_sets.txt
+i=0
+for set in "$SQ1" "$SQ2" "$T1" "$T2" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  [ -z "$set" ] && continue
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $out/pmc4m_$i -- $B > $out/pmc4m_$i.log 2>&1 || echo "pmc pass $i ($set) failed" >> $out/pmc_sets.txt
+done
+python3 tools/pmc_summary4m.py $out > $out/pmc4m_summary.json 2> $out/pmc4m_summary.err
+for nt in 0 1; do
+  echo "TT_NT_ENVS=$nt" >> $out/step_nt.txt
+  TT_NT_ENVS=$nt timeout -k 10 200 python3 tools/ab_kernel.py 65536 1048576 4194304 >> $out/step_nt.txt 2>&1
+done
+fi
 ls $out | head -80
