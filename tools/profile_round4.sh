@@ -25,6 +25,9 @@ TT_LIB_PATH=$STAMPS timeout -k 10 300 python3 tools/step_timeline.py > $out/step
 python3 tools/time_actor_cap.py > $out/time_actor_cap.txt 2>&1
 timeout -k 10 400 python3 tools/soak.py 65536 200000 > $out/soak.txt 2>&1 || echo "soak failed"
 if [ "${PMC4M:-0}" = "1" ]; then      # what bounds k_step at N = 4 M envs (round 3's study: kernel trace + SQ / TCC / FETCH / WRITE passes, each its own run)
+N=4194304
+B="python3 bench.py --workload env --n-envs $N --graph-steps 1 --steps 40 --warmup 10 --no-cpu-baseline --repeats 0"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/env4m -- $B > $out/env4m.log 2>&1 || echo "env4m trace failed"
 rocprofv3 -L > $out/counters.txt 2>&1
 SQ1=$(python3 tools/pmc_pick.py $out/counters.txt 8 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU)
 SQ2=$(python3 tools/pmc_pick.py $out/counters.txt 8 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS)
