@@ -149,6 +149,9 @@ _SIGNATURES = {
     "tt_mlp_backward_weights": (C.c_int, [_I, _I, _P, _P, C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs), C.POINTER(TTMlpWeights),
                                           _P, _P, C.c_float, _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                           C.c_float, C.c_float, C.POINTER(TTFc2Images), _P, _P]),
+    "tt_mlp_actor_tail": (C.c_int, [_I, _P, _P, C.POINTER(TTMlpWeights), _P, _P, C.POINTER(TTMlpSaved), C.POINTER(TTMlpBwdWs),
+                                    C.POINTER(TTMlpWeights), C.c_float, _I, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, C.POINTER(TTFc2Images), _P, _P, _P, _P]),
     "tt_adam_soft_update": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                       C.c_float, C.c_float, C.POINTER(TTFc2Images), _P, _P]),
     "tt_p2p_create": (C.c_int, [_I, _I, _I, _I, _P, C.POINTER(_P)]),

@@ -268,7 +268,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
                                                float *__restrict__ z_s, float *__restrict__ w1_s, const int row0,
                                                const float *__restrict__ obs_row_lane = nullptr,
                                                const bool act_given = false, const float act_row0 = 0.f,
-                                               const float act_row1 = 0.f) {
+                                               const float act_row1 = 0.f, const bool dq_atomic = false) {
     // obs_row_lane (optional): this lane's observation row for layer 1 (row row0 + (lane & 15)) when the rows are gathered
     // from a replay ring instead of read from obs [n,23]; act_given / act_row0, 1: the actions of this wave's two rows likewise.
     // h1_s [16][404]: fc1 pre-activations, then the A operand of layer 2; z_s [16][308]: fc2 pre-activations.
@@ -614,7 +614,11 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
         if (lane == 0 && row < n) {
             const float v = dot + b3;
             out[row] = CRITIC ? v : tanhf(v);
-            if (CRITIC && dq_da) dq_da[row] = dqa;
+            if (CRITIC && dq_da) {
+                // (k_actor_tail: read by workgroups of the SAME launch on other XCDs -- an agent-scope atomic store is coherent by itself)
+                if (dq_atomic) __hip_atomic_store(dq_da + row, dqa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else dq_da[row] = dqa;
+            }
         }
     }
     STAMP(4);
@@ -1239,25 +1243,55 @@ constexpr int SUMB_CRITIC = SUMB_ACTOR + 2 * 5;
 // round trips per workgroup; this one has one.
 constexpr int KCH = 4;                              // k16 steps per chunk of a wave's batch rows
 // (register budget: <= 168, three workgroups per CU -- beside the policy's grid only ~85 CUs are free for the ~205 of this launch)
-template <bool ROWSCALE>
-__global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int critic, const float *__restrict__ obs,
-                                                     const float *__restrict__ action, const Saved sv,
-                                                     const BwdOut d, const Grads G, const AdamFused A, const RowScale RS) {
-    __shared__ __attribute__((aligned(16))) float part[4][4][256];     // [wave][tile][lane*4 + r]
-    __shared__ float f_s[ROWSCALE ? MAXB : 1];                         // the rows' factors, computed once per workgroup
+// Hand-over of dQ/da INSIDE one launch (k_actor_tail below): the row workgroups of Q(s, mu(s)) publish, the weight-gradient
+// workgroups of the same grid -- everything else they need already requested -- wait.  words[w] = the learn step whose dQ/da rows
+// of producer workgroup w are complete (stored after its rows' values, which leave as agent-scope atomic stores: coherent across
+// the XCDs by themselves, no cache maintenance on either side); the consumers read dQ/da with agent-scope atomic loads.
+struct TailSync {
+    int *words;                 // [producers] device ints (nullptr: no hand-over, dQ/da is complete when the launch starts)
+    int producers;
+    int *gave_up_host;          // one int of pinned host memory: set (system scope) by a consumer that stopped waiting
+};
+__device__ __forceinline__ void tail_wait(const TailSync &ts, const int epoch) {      // the first wave of the workgroup calls this
+    const int lane = threadIdx.x & 63;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        const int v = lane < ts.producers ? __hip_atomic_load(ts.words + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+        if (__all(v == epoch)) break;
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > ttnet::TT_IMAGE_WAIT_TICKS) {      // never hang: mark (host-visible) and go on; the caller raises
+            if (lane == 0 && ts.gave_up_host) __hip_atomic_store(ts.gave_up_host, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+}
+
+template <bool ROWSCALE, bool TAIL>
+__device__ __forceinline__ void bwd_weights_body(const int blk, const int n, const int critic, const float *__restrict__ obs,
+                                                 const float *__restrict__ action, const Saved &sv, const BwdOut &d, const Grads &G,
+                                                 const AdamFused &A, const RowScale &RS, float (&part)[4][4][256],
+                                                 float *__restrict__ f_s, const TailSync &ts, const long long tail_epoch) {
     auto fill_factors = [&]() __attribute__((always_inline)) {       // every thread of the workgroup calls this once
         if (ROWSCALE) {
-            for (int b = threadIdx.x; b < n; b += 256) {
-                const float m = RS.mu[b];
-                f_s[b] = RS.scale * RS.dq_da[b] * (1.f - m * m);
+            if (TAIL && ts.words) {
+                // everything else this workgroup reads is in flight by now: wait for the producers' rows of THIS learn step
+                if (threadIdx.x < 64) tail_wait(ts, (int)tail_epoch);
+                lds_barrier();
+                for (int b = threadIdx.x; b < n; b += 256) {
+                    const float m = RS.mu[b];
+                    f_s[b] = RS.scale * __hip_atomic_load(RS.dq_da + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (1.f - m * m);
+                }
+            } else {
+                for (int b = threadIdx.x; b < n; b += 256) {
+                    const float m = RS.mu[b];
+                    f_s[b] = RS.scale * RS.dq_da[b] * (1.f - m * m);
+                }
             }
             lds_barrier();
         }
     };
     auto row_factor = [&](const int b) -> float { return ROWSCALE ? f_s[b] : 1.f; };
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-    const int blk = blockIdx.x;
-    kernarg_warm<24 + (int)sizeof(Saved) + (int)sizeof(BwdOut) + (int)sizeof(Grads) + (int)sizeof(AdamFused) + (int)sizeof(RowScale)>();
     KBEGIN(ROWSCALE ? 4 : 2);
     STAMPB(12, 0); STAMPB(14, NU2); STAMPB(5, NU2 + NU1);
 #ifdef TT_STAMPS
@@ -1606,6 +1640,48 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
 #endif
     }
     KEND(ROWSCALE ? 4 : 2);
+}
+
+template <bool ROWSCALE>
+__global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int critic, const float *__restrict__ obs,
+                                                     const float *__restrict__ action, const Saved sv,
+                                                     const BwdOut d, const Grads G, const AdamFused A, const RowScale RS) {
+    __shared__ __attribute__((aligned(16))) float part[4][4][256];     // [wave][tile][lane*4 + r]
+    __shared__ float f_s[ROWSCALE ? MAXB : 1];                         // the rows' factors, computed once per workgroup
+    kernarg_warm<24 + (int)sizeof(Saved) + (int)sizeof(BwdOut) + (int)sizeof(Grads) + (int)sizeof(AdamFused) + (int)sizeof(RowScale)>();
+    bwd_weights_body<ROWSCALE, false>(blockIdx.x, n, critic, obs, action, sv, d, G, A, RS, part, f_s, TailSync{nullptr, 0, nullptr}, 0);
+}
+
+// learn()'s last two launches in ONE grid (the single-rank chain where the policy launch is small or learn() repeats per step):
+// workgroups [0, nb) are k_fwd_small<critic> on (s, mu(s)) -- Q(s, mu(s)) and dQ/da through the UPDATED critic (DDPG_agent.py:100-103)
+// --, the rest are k_bwd_weights<actor>, which request their operands, optimizer state and step count at once as always and then
+// wait for the row workgroups' dQ/da in device memory (TailSync) instead of behind a launch boundary: the boundary (1.5-1.9 us),
+// the kernel entry and the operand round trip of the weight-gradient launch leave learn()'s chain.  The row workgroups are
+// dispatched first, so they never wait for a CU behind the workgroups that wait for them.  512 threads per workgroup (the row
+// kernel's geometry); a weight-gradient workgroup uses the first 256.  LDS: the row kernel's tiles and the weight kernel's share it.
+__global__ __launch_bounds__(64 * NW) void k_actor_tail(const int n, const float *__restrict__ obs, const float *__restrict__ mu,
+                                                        const Weights Wc, float *__restrict__ q_out, float *__restrict__ dq_da,
+                                                        const Saved sv, const BwdOut d, const Grads G, const AdamFused A,
+                                                        const RowScale RS, const TailSync ts) {
+    __shared__ __attribute__((aligned(16))) float lds[H1S_FLOATS + TR * DS + H1 * IN];
+    const int nb = (n + TR - 1) / TR;
+    if ((int)blockIdx.x < nb) {
+        const Saved none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        const long long epoch = *A.step_dev;
+        KBEGIN(3);
+        fwd_small_body<true>(n, obs, mu, Wc, q_out, none, dq_da, nullptr, lds, lds + H1S_FLOATS, lds + H1S_FLOATS + TR * DS,
+                             blockIdx.x * TR, nullptr, false, 0.f, 0.f, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its rows' dQ/da have been written
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(ts.words + blockIdx.x, (int)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        KEND(3);
+        return;
+    }
+    if (threadIdx.x >= 256) return;
+    static_assert(sizeof(float) * (H1S_FLOATS + TR * DS + H1 * IN) >= sizeof(float) * (4 * 4 * 256 + MAXB), "the weight kernel's LDS fits");
+    float (&part)[4][4][256] = *reinterpret_cast<float (*)[4][4][256]>(lds);
+    const long long epoch = *A.step_dev;
+    bwd_weights_body<true, true>((int)blockIdx.x - nb, n, 0, obs, nullptr, sv, d, G, A, RS, part, lds + 4 * 4 * 256, ts, epoch);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2063,6 +2139,39 @@ int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *ac
     } else {
         hipLaunchKernelGGL(k_bwd_weights<false>, grid, dim3(256), 0, stream, n, critic, obs, action, sv, o, to_grads(grads), A, rs);
     }
+    return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
+}
+
+int tt_mlp_actor_tail(int n, const float *obs, const float *mu, const tt_mlp_weights *critic, float *q_out, float *dq_da,
+                      const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, float row_scale, int count,
+                      float *const *params, float *const *exp_avg, float *const *exp_avg_sq, float *const *targets,
+                      const int64_t *step_dev, float lr, float beta1, float beta2, float eps, float weight_decay, float tau,
+                      const tt_fc2_images *images, const float *bias_corr, int32_t *tail_words, int32_t *gave_up_host,
+                      tt_stream_t stream) {
+    if (n <= 0 || n > MAXB || !obs || !mu || !q_out || !dq_da || !ok_shape(critic, true) || !saved_ok(saved) || !ws_ok(ws) ||
+        !ok_shape(grads, false) || count != 10 || !params || !exp_avg || !exp_avg_sq || !step_dev || !tail_words)
+        return TT_EINVAL;
+    const int nb = (n + TR - 1) / TR;
+    if (nb > 64) return TT_EINVAL;                         // (one wave polls the producers' words)
+    AdamFused A{};
+    for (int i = 0; i < count; ++i) {
+        if (!params[i] || !exp_avg[i] || !exp_avg_sq[i]) return TT_EINVAL;
+        A.p[i] = params[i]; A.m[i] = exp_avg[i]; A.v[i] = exp_avg_sq[i]; A.tgt[i] = targets ? targets[i] : nullptr;
+    }
+    A.step_dev = reinterpret_cast<const long long *>(step_dev);
+    A.lr = lr; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.weight_decay = weight_decay; A.tau = tau;
+    A.on = 1;
+    A.bias_corr = bias_corr;
+    if (images) {
+        A.img_p = reinterpret_cast<_Float16 *>(images->net);
+        A.img_t = reinterpret_cast<_Float16 *>(images->target);
+    }
+    const Saved sv{saved->xh1, saved->h1, saved->xh2, saved->h2, saved->rstd1, saved->rstd2};
+    const BwdOut o{ws->dpre, ws->dz, ws->dx2, ws->dy1, ws->dx1};
+    const RowScale rs{dq_da, mu, row_scale};
+    const TailSync ts{tail_words, nb, gave_up_host};
+    hipLaunchKernelGGL(k_actor_tail, dim3(nb + NU2 + NU1 + SUMB_ACTOR), dim3(64 * NW), 0, stream, n, obs, mu, to_weights(critic), q_out,
+                       dq_da, sv, o, to_grads(grads), A, rs, ts);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
 

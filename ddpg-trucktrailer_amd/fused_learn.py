@@ -130,6 +130,12 @@ class FusedLearner:
         self.z_t = torch.empty((B, 300), **f)          # the target critic's state branch on s' (before the action enters)
         self.grad_sync_critic = self.grad_sync_actor = None
         self.p2p = None                    # the peer-to-peer gradient exchange (enable_p2p), a tt_p2p handle
+        # learn()'s last two launches in ONE grid (tt_mlp_actor_tail): dQ/da is handed to the actor's weight-gradient workgroups in
+        # device memory.  For the configurations learn() bounds (a small policy launch, several updates per step): its 200 waiting
+        # workgroups would crowd a policy launch that owns 171 CUs.  Set by the loop (DDPGRollout), off by default.
+        self.fuse_tail = False
+        self.tail_words = torch.full((64,), -1, dtype=torch.int32, device=dev)
+        self.tail_gave_up_host = torch.zeros(2, dtype=torch.int32).pin_memory() if dev.type == "cuda" else None
         ga, gc = agent.actor.optimizer.param_groups[0], agent.critic.optimizer.param_groups[0]
         self.hyp_actor = (ga["lr"], ga["betas"][0], ga["betas"][1], ga["eps"], ga["weight_decay"])
         self.hyp_critic = (gc["lr"], gc["betas"][0], gc["betas"][1], gc["eps"], gc["weight_decay"])
@@ -276,6 +282,11 @@ class FusedLearner:
             st.bind_flat_grad(_device_view(self.lib.tt_p2p_grad(h, site), st.flat_grad.numel(), self.dev, owner=self))
         self.grad_sync_critic = self.grad_sync_actor = _no_sync       # (learn_batch's data-parallel order: separate Adam launches)
 
+    def tail_gave_up(self):
+        """0, or the learn step at which a weight-gradient workgroup of tt_mlp_actor_tail stopped waiting for dQ/da (that learn() is
+        garbage).  Reads host memory only."""
+        return int(self.tail_gave_up_host[0]) if self.tail_gave_up_host is not None else 0
+
     def p2p_gave_up(self):
         """0, or the learn step at which this rank's Adam launch stopped waiting for a peer's gradients (it then used whatever the
         buffers held: the ranks have diverged).  Reads host memory only."""
@@ -363,6 +374,16 @@ class FusedLearner:
         ag, B = self.agent, self.B
         if separate_adam:
             self._adam(self.critic, self.hyp_critic, ag.tau)
+        elif self.fuse_tail:
+            self._fresh()
+            st = self.actor
+            lr, b1, b2, eps, wd = self.hyp_actor
+            L.check(self.lib.tt_mlp_actor_tail(B, _p(states), _p(self.mu), C.byref(self.w(ag.critic)), _p(self.q_pi), _p(self.dq_da),
+                                               C.byref(st.saved), C.byref(self.ws_actor), C.byref(st.gstruct), -1.0 / B, st.count,
+                                               st.a_p, st.a_m, st.a_v, st.a_t, _p(self.step_dev), lr, b1, b2, eps, wd, ag.tau,
+                                               C.byref(st.images) if st.images is not None else None, _p(self.bias_corr),
+                                               _p(self.tail_words), C.c_void_p(self.tail_gave_up_host.data_ptr()), self._stream()))
+            return
         self._fwd(ag.critic, states, self.mu, self.q_pi, dq_da=self.dq_da)
         self._weights(self.actor, self.hyp_actor, ag.tau, states, None, self.ws_actor, adam=not separate_adam,
                       row=(self.dq_da, self.mu, -1.0 / B))
@@ -397,6 +418,7 @@ class FusedLearner:
             st = getattr(self, name)
             st.m.copy_(sd[name]["m"]); st.v.copy_(sd[name]["v"])
         self.step_dev.fill_(int(sd["step"]))
+        self.tail_words.fill_(-1)          # (tt_mlp_actor_tail: words of an earlier run must not match a step number set back)
         self.p2p_reset()
 
     # ---- checkpoint interoperability with the torch optimizers ------------------------------------------

@@ -115,6 +115,12 @@ class DDPGRollout:
                 self.dp_single_graph = True              # nothing but kernel launches in a step: one graph, any backend
             elif self.dp:
                 self.learner.enable_data_parallel()
+        if self.learner is not None and not self.dp and self.device.type == "cuda":
+            # learn()'s last two launches as one grid where learn() bounds the step (include/ttenv.h: tt_mlp_actor_tail): a policy
+            # launch of at most one round of 128 tiles, or several updates per step (at N = 65536 with one update per step the grid's 200
+            # waiting workgroups meet a policy launch that owns 171 CUs: 0.084 -> 0.094 ms per step).  TT_ACTOR_TAIL=0/1 overrides.
+            tail = os.environ.get("TT_ACTOR_TAIL")
+            self.learner.fuse_tail = (tail == "1") if tail in ("0", "1") else (self.n <= 16384 or self.updates_per_step > 1)
         if self.dp and self.dp_exchange == "p2p" and self.learner is None:
             raise RuntimeError("dp_exchange='p2p' needs the fused learner (reference-shaped networks on a GPU)")
         self.use_graph = use_graph and self.device.type == "cuda"
@@ -316,6 +322,10 @@ class DDPGRollout:
         again with graph edges between the chains (what bench.py does in its setup: ~4 us per step slower, never waits).  A
         second time -- with edges no launch ever has to wait -- is an error."""
         ring = self.ring
+        if self.learner is not None and self.learner.tail_gave_up():
+            raise RuntimeError(f"learn step {self.learner.tail_gave_up()}: a weight-gradient workgroup of learn()'s last launch gave up waiting "
+                               "(0.25 s) for dQ/da from the row workgroups of the same launch (include/ttenv.h: tt_mlp_actor_tail) and "
+                               "went on: that update is garbage.  TT_ACTOR_TAIL=0 runs the two launches apart")
         if self.learner is not None and self.learner.p2p_gave_up():
             raise RuntimeError(f"learn step {self.learner.p2p_gave_up()}: this rank's optimizer launch gave up waiting for a peer's gradients "
                                "(peer-to-peer exchange, include/ttenv.h: tt_p2p_*) and used whatever the buffers held: the ranks have "

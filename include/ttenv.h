@@ -486,6 +486,20 @@ int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *ac
                             float weight_decay, float tau, const tt_fc2_images *images /* may be NULL */,
                             const float *bias_corr /* tt_td_input.bias_corr_out or NULL */, tt_stream_t stream);
 
+/* The last two launches of the single-rank sequence above in ONE grid: tt_mlp_forward_save(critic on (s, mu), dq_da) and
+ * tt_mlp_backward_weights(actor, row_dq_da = dq_da, row_mu = mu, row_scale, Adam + soft update + images).  The weight-gradient
+ * workgroups request everything else they read, then wait IN DEVICE MEMORY for the row workgroups' dQ/da (one word per row
+ * workgroup: tail_words [ceil(n / 16)] device ints, written with the learn step *step_dev; the caller sets them to -1 whenever it
+ * sets *step_dev back) instead of behind a launch boundary.  The wait is bounded (0.25 s): a workgroup that gives up stores the
+ * step into *gave_up_host (one int of device-visible host memory, may be NULL) and goes on -- the caller must treat that learn()
+ * as failed.  Same results as the two launches, bit for bit.  n <= 1024 rows. */
+int tt_mlp_actor_tail(int n, const float *obs, const float *mu, const tt_mlp_weights *critic, float *q_out, float *dq_da,
+                      const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, float row_scale, int count,
+                      float *const *params, float *const *exp_avg, float *const *exp_avg_sq, float *const *targets,
+                      const int64_t *step_dev, float lr, float beta1, float beta2, float eps, float weight_decay, float tau,
+                      const tt_fc2_images *images, const float *bias_corr, int32_t *tail_words, int32_t *gave_up_host,
+                      tt_stream_t stream);
+
 /* optimizer.step() of torch.optim.Adam (weight decay folded into the gradient; networks.py:49-50,133) for `count`
  * (<= 12) parameter tensors in one launch, then the soft update of the matching target tensors
  * (Agent.update_network_parameters, DDPG_agent.py:108-131; targets NULL = none).  The arrays are HOST arrays of device

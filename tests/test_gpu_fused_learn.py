@@ -414,3 +414,57 @@ def test_policy_image_packed_by_learns_second_launch(gpu_device):
         cw = ring.cursor_dev.cpu().tolist()
         assert cw[4 + 4 * (k & 1): 8 + 4 * (k & 1)] == [k % slots, (k + 1) % slots, (k - 1) % slots, 1]
         assert cw[12 + (k & 1)] == k + 1 and cw[14] == 0 and cw[15] == 0
+
+
+@pytest.mark.parametrize("images", [True, False])
+def test_actor_tail_in_one_launch_equals_the_two_launches(gpu_device, images):
+    """tt_mlp_actor_tail: Q(s, mu(s)) / dQ/da through the updated critic and the actor's weight gradients + Adam + soft update + image
+    patches in ONE grid -- dQ/da handed from the row workgroups to the weight-gradient workgroups in device memory (agent-scope
+    atomics, one epoch word per row workgroup) -- against the same two launches apart: every weight, both targets, the Adam
+    moments, the flat gradients and q / dQ/da after 4 learn() calls on fixture F5's batch, bit for bit; also as a replayed hipGraph;
+    the give-up word stays clear; a step counter set back (resume) does not match stale epoch words."""
+    import torch
+    from conftest import GOLDEN
+    from ddpg_trucktrailer_amd.fused_learn import FusedLearner
+    from test_learner import _batch
+    z = np.load(os.path.join(GOLDEN, "f5_learner.npz"), allow_pickle=False)
+    s, a, r, s2, d = _batch(z, gpu_device)
+    d8 = d.to(torch.uint8)
+    outs = []
+    for tail, graph in ((False, False), (True, False), (True, True)):
+        agent = _agent(gpu_device, z)
+        fl = FusedLearner(agent, 256, fc2_images=images)
+        fl.fuse_tail = tail
+        fl.learn_batch(s, a, r, s2, d8)
+        if graph:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.graph(g, stream=side):
+                fl.learn_batch(s, a, r, s2, d8)
+            torch.cuda.current_stream().wait_stream(side)
+            for _ in range(3):
+                g.replay()
+        else:
+            for _ in range(3):
+                fl.learn_batch(s, a, r, s2, d8)
+        torch.cuda.synchronize()
+        assert fl.tail_gave_up() == 0 and int(fl.step_dev.item()) == 4
+        if tail:
+            assert fl.tail_words[:16].cpu().tolist() == [4] * 16 and fl.tail_words[16:].eq(-1).all()
+        flat = torch.cat([p.detach().reshape(-1) for net in agent._nets() for p in net.parameters()])
+        outs.append((flat.clone(), fl.actor.m.clone(), fl.actor.v.clone(), fl.critic.m.clone(), fl.actor.flat_grad.clone(),
+                     fl.q_pi.clone(), fl.dq_da.clone()))
+        if tail and not graph:      # resume to an earlier step: the words are cleared, the next learn() waits for ITS producers
+            sd = fl.state_dict()
+            sd["step"] = 3
+            fl.load_state_dict(sd)
+            assert fl.tail_words.eq(-1).all()
+            fl.learn_batch(s, a, r, s2, d8)
+            torch.cuda.synchronize()
+            assert fl.tail_gave_up() == 0 and int(fl.step_dev.item()) == 4 and torch.isfinite(fl.dq_da).all()
+    for k in (1, 2):
+        for x, y in zip(outs[0], outs[k]):
+            assert torch.equal(x, y), ("eager" if k == 1 else "graph")
+    assert torch.isfinite(outs[0][0]).all()

@@ -1,7 +1,8 @@
 """GPU: what the data-parallel learn() costs a rank per update before any time on the wire -- the five launches + the two
 optimizer launches, captured as one hipGraph and replayed back to back -- with (a) no exchange at all (k_adam_soft after a no-op),
 (b) the peer-to-peer exchange at world size 1 (k_adam_soft_p2p: publish, wait, acquire, gradient read from the exchange block),
-and, for reference, (c) the single-rank learn() whose Adam runs inside the weight-gradient launches."""
+and, for reference, (c) the single-rank learn() whose Adam runs inside the weight-gradient launches -- with its last two launches apart
+("fused") and as one grid ("fused+tail": tt_mlp_actor_tail)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,6 +19,8 @@ def make(kind):
     fl = FusedLearner(ag, B)
     if kind == "p2p":
         fl.enable_p2p()
+    elif kind == "fused+tail":
+        fl.fuse_tail = True
     elif kind == "separate":
         fl.grad_sync_critic = fl.grad_sync_actor = lambda: None
     return fl
@@ -49,5 +52,5 @@ def time_graph(fl, reps=300):
     return min(out)
 
 
-for kind in ("fused", "separate", "p2p"):
-    print(f"{kind:9s} learn() per update, back-to-back graph replays: {time_graph(make(kind)):.2f} us", flush=True)
+for kind in ("fused", "fused+tail", "separate", "p2p"):
+    print(f"{kind:10s} learn() per update, back-to-back graph replays: {time_graph(make(kind)):.2f} us", flush=True)
