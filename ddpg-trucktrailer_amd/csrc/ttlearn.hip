@@ -268,7 +268,8 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
                                                float *__restrict__ z_s, float *__restrict__ w1_s, const int row0,
                                                const float *__restrict__ obs_row_lane = nullptr,
                                                const bool act_given = false, const float act_row0 = 0.f,
-                                               const float act_row1 = 0.f, const bool dq_atomic = false) {
+                                               const float act_row1 = 0.f, unsigned long long *dq_words = nullptr,
+                                               const unsigned dq_epoch = 0u) {
     // obs_row_lane (optional): this lane's observation row for layer 1 (row row0 + (lane & 15)) when the rows are gathered
     // from a replay ring instead of read from obs [n,23]; act_given / act_row0, 1: the actions of this wave's two rows likewise.
     // h1_s [16][404]: fc1 pre-activations, then the A operand of layer 2; z_s [16][308]: fc2 pre-activations.
@@ -615,9 +616,13 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
             const float v = dot + b3;
             out[row] = CRITIC ? v : tanhf(v);
             if (CRITIC && dq_da) {
-                // (k_actor_tail: read by workgroups of the SAME launch on other XCDs -- an agent-scope atomic store is coherent by itself)
-                if (dq_atomic) __hip_atomic_store(dq_da + row, dqa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else dq_da[row] = dqa;
+                dq_da[row] = dqa;
+                // k_actor_tail: read by workgroups of the SAME launch on other XCDs.  Value and learn step leave as ONE 8-byte atomic
+                // store (agent scope: coherent by itself), so a reader that finds the step it waits for has the value of that step
+                // -- no second word whose store could overtake the value's on its way to memory, hence no release fence.
+                if (dq_words)
+                    __hip_atomic_store(dq_words + row, ((unsigned long long)dq_epoch << 32) | (unsigned long long)__float_as_uint(dqa),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -1244,26 +1249,42 @@ constexpr int SUMB_CRITIC = SUMB_ACTOR + 2 * 5;
 constexpr int KCH = 4;                              // k16 steps per chunk of a wave's batch rows
 // (register budget: <= 168, three workgroups per CU -- beside the policy's grid only ~85 CUs are free for the ~205 of this launch)
 // Hand-over of dQ/da INSIDE one launch (k_actor_tail below): the row workgroups of Q(s, mu(s)) publish, the weight-gradient
-// workgroups of the same grid -- everything else they need already requested -- wait.  words[w] = the learn step whose dQ/da rows
-// of producer workgroup w are complete (stored after its rows' values, which leave as agent-scope atomic stores: coherent across
-// the XCDs by themselves, no cache maintenance on either side); the consumers read dQ/da with agent-scope atomic loads.
+// workgroups of the same grid -- everything else they need already requested -- wait.  Per ROW one 8-byte word {learn step, dQ/da}
+// written by ONE agent-scope atomic store and read by one agent-scope atomic load: a reader that sees the step has the value, with
+// no ordering between two locations to rely on and no cache maintenance on either side.  Per row WORKGROUP one hint word (the
+// learn step, stored after the rows' words): a consumer polls the 16 hints with one wave before its 256 threads look at the rows,
+// so that 200 waiting workgroups do not hammer 256 words; the hints prove nothing, the rows' words do.
 struct TailSync {
-    int *words;                 // [producers] device ints (nullptr: no hand-over, dQ/da is complete when the launch starts)
+    int *hints;                          // [64] device ints (nullptr: no hand-over, dQ/da is complete when the launch starts)
+    unsigned long long *rows;            // [n] {step << 32 | float bits of dQ/da}
     int producers;
-    int *gave_up_host;          // one int of pinned host memory: set (system scope) by a consumer that stopped waiting
+    int *gave_up_host;                   // one int of pinned host memory: set (system scope) by a consumer that stopped waiting
 };
-__device__ __forceinline__ void tail_wait(const TailSync &ts, const int epoch) {      // the first wave of the workgroup calls this
+__device__ __forceinline__ void tail_wait_hints(const TailSync &ts, const int epoch) {      // the first wave of the workgroup calls this
     const int lane = threadIdx.x & 63;
     const unsigned long long t0 = wall_clock64();
     for (;;) {
-        const int v = lane < ts.producers ? __hip_atomic_load(ts.words + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+        const int v = lane < ts.producers ? __hip_atomic_load(ts.hints + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
         if (__all(v == epoch)) break;
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > ttnet::TT_IMAGE_WAIT_TICKS) {      // never hang: mark (host-visible) and go on; the caller raises
-            if (lane == 0 && ts.gave_up_host) __hip_atomic_store(ts.gave_up_host, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
-        }
+        if (wall_clock64() - t0 > ttnet::TT_IMAGE_WAIT_TICKS) break;      // (the rows' words decide, below)
     }
+}
+// dQ/da of row b for learn step `epoch` (bounded: never hang -- mark, host-visible, and go on; the caller raises)
+__device__ __forceinline__ float tail_row(const TailSync &ts, const int b, const int epoch) {
+    unsigned long long w = __hip_atomic_load(ts.rows + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)(w >> 32) != epoch) {
+        const unsigned long long t0 = wall_clock64();
+        do {
+            __builtin_amdgcn_s_sleep(8);
+            w = __hip_atomic_load(ts.rows + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wall_clock64() - t0 > ttnet::TT_IMAGE_WAIT_TICKS) {
+                if (ts.gave_up_host) __hip_atomic_store(ts.gave_up_host, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        } while ((int)(w >> 32) != epoch);
+    }
+    return __uint_as_float((unsigned)w);
 }
 
 template <bool ROWSCALE, bool TAIL>
@@ -1273,13 +1294,13 @@ __device__ __forceinline__ void bwd_weights_body(const int blk, const int n, con
                                                  float *__restrict__ f_s, const TailSync &ts, const long long tail_epoch) {
     auto fill_factors = [&]() __attribute__((always_inline)) {       // every thread of the workgroup calls this once
         if (ROWSCALE) {
-            if (TAIL && ts.words) {
+            if (TAIL && ts.hints) {
                 // everything else this workgroup reads is in flight by now: wait for the producers' rows of THIS learn step
-                if (threadIdx.x < 64) tail_wait(ts, (int)tail_epoch);
+                if (threadIdx.x < 64) tail_wait_hints(ts, (int)tail_epoch);
                 lds_barrier();
                 for (int b = threadIdx.x; b < n; b += 256) {
                     const float m = RS.mu[b];
-                    f_s[b] = RS.scale * __hip_atomic_load(RS.dq_da + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (1.f - m * m);
+                    f_s[b] = RS.scale * tail_row(ts, b, (int)tail_epoch) * (1.f - m * m);
                 }
             } else {
                 for (int b = threadIdx.x; b < n; b += 256) {
@@ -1649,7 +1670,7 @@ __global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int crit
     __shared__ __attribute__((aligned(16))) float part[4][4][256];     // [wave][tile][lane*4 + r]
     __shared__ float f_s[ROWSCALE ? MAXB : 1];                         // the rows' factors, computed once per workgroup
     kernarg_warm<24 + (int)sizeof(Saved) + (int)sizeof(BwdOut) + (int)sizeof(Grads) + (int)sizeof(AdamFused) + (int)sizeof(RowScale)>();
-    bwd_weights_body<ROWSCALE, false>(blockIdx.x, n, critic, obs, action, sv, d, G, A, RS, part, f_s, TailSync{nullptr, 0, nullptr}, 0);
+    bwd_weights_body<ROWSCALE, false>(blockIdx.x, n, critic, obs, action, sv, d, G, A, RS, part, f_s, TailSync{nullptr, nullptr, 0, nullptr}, 0);
 }
 
 // learn()'s last two launches in ONE grid (the single-rank chain where the policy launch is small or learn() repeats per step):
@@ -1670,10 +1691,10 @@ __global__ __launch_bounds__(64 * NW) void k_actor_tail(const int n, const float
         const long long epoch = *A.step_dev;
         KBEGIN(3);
         fwd_small_body<true>(n, obs, mu, Wc, q_out, none, dq_da, nullptr, lds, lds + H1S_FLOATS, lds + H1S_FLOATS + TR * DS,
-                             blockIdx.x * TR, nullptr, false, 0.f, 0.f, true);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its rows' dQ/da have been written
+                             blockIdx.x * TR, nullptr, false, 0.f, 0.f, ts.rows, (unsigned)epoch);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its rows' words have been sent
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(ts.words + blockIdx.x, (int)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(ts.hints + blockIdx.x, (int)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         KEND(3);
         return;
     }
@@ -2169,7 +2190,8 @@ int tt_mlp_actor_tail(int n, const float *obs, const float *mu, const tt_mlp_wei
     const Saved sv{saved->xh1, saved->h1, saved->xh2, saved->h2, saved->rstd1, saved->rstd2};
     const BwdOut o{ws->dpre, ws->dz, ws->dx2, ws->dy1, ws->dx1};
     const RowScale rs{dq_da, mu, row_scale};
-    const TailSync ts{tail_words, nb, gave_up_host};
+    // tail_words: [0, 64) the row workgroups' hints, [64, 64 + 2 n) the rows' 8-byte words
+    const TailSync ts{tail_words, reinterpret_cast<unsigned long long *>(tail_words + 64), nb, gave_up_host};
     hipLaunchKernelGGL(k_actor_tail, dim3(nb + NU2 + NU1 + SUMB_ACTOR), dim3(64 * NW), 0, stream, n, obs, mu, to_weights(critic), q_out,
                        dq_da, sv, o, to_grads(grads), A, rs, ts);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;

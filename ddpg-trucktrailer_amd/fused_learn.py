@@ -134,7 +134,7 @@ class FusedLearner:
         # device memory.  For the configurations learn() bounds (a small policy launch, several updates per step): its 200 waiting
         # workgroups would crowd a policy launch that owns 171 CUs.  Set by the loop (DDPGRollout), off by default.
         self.fuse_tail = False
-        self.tail_words = torch.full((64,), -1, dtype=torch.int32, device=dev)
+        self.tail_words = torch.full((64 + 2 * 1024,), -1, dtype=torch.int32, device=dev)      # hints + one {step, dQ/da} word per row
         self.tail_gave_up_host = torch.zeros(2, dtype=torch.int32).pin_memory() if dev.type == "cuda" else None
         ga, gc = agent.actor.optimizer.param_groups[0], agent.critic.optimizer.param_groups[0]
         self.hyp_actor = (ga["lr"], ga["betas"][0], ga["betas"][1], ga["eps"], ga["weight_decay"])

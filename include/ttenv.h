@@ -488,11 +488,13 @@ int tt_mlp_backward_weights(int n, int critic, const float *obs, const float *ac
 
 /* The last two launches of the single-rank sequence above in ONE grid: tt_mlp_forward_save(critic on (s, mu), dq_da) and
  * tt_mlp_backward_weights(actor, row_dq_da = dq_da, row_mu = mu, row_scale, Adam + soft update + images).  The weight-gradient
- * workgroups request everything else they read, then wait IN DEVICE MEMORY for the row workgroups' dQ/da (one word per row
- * workgroup: tail_words [ceil(n / 16)] device ints, written with the learn step *step_dev; the caller sets them to -1 whenever it
- * sets *step_dev back) instead of behind a launch boundary.  The wait is bounded (0.25 s): a workgroup that gives up stores the
- * step into *gave_up_host (one int of device-visible host memory, may be NULL) and goes on -- the caller must treat that learn()
- * as failed.  Same results as the two launches, bit for bit.  n <= 1024 rows. */
+ * workgroups request everything else they read, then wait IN DEVICE MEMORY for the row workgroups' dQ/da instead of behind a launch
+ * boundary.  tail_words: 64 + 2 n device ints, set to -1 by the caller at creation and whenever it sets *step_dev back: [0, 64) one
+ * hint word per row workgroup, [64, 64 + 2 n) per ROW one 8-byte word {learn step *step_dev, float bits of dQ/da} written by ONE
+ * agent-scope atomic store -- a reader that finds the step it waits for holds the value of that step, so the hand-over needs no
+ * ordering between two locations and no cache maintenance.  The wait is bounded (0.25 s): a thread that gives up stores the step
+ * into *gave_up_host (one int of device-visible host memory, may be NULL) and goes on -- the caller must treat that learn() as
+ * failed.  Same results as the two launches, bit for bit (dq_da [n] is written as well).  n <= 1024 rows. */
 int tt_mlp_actor_tail(int n, const float *obs, const float *mu, const tt_mlp_weights *critic, float *q_out, float *dq_da,
                       const tt_mlp_saved *saved, const tt_mlp_bwd_ws *ws, const tt_mlp_weights *grads, float row_scale, int count,
                       float *const *params, float *const *exp_avg, float *const *exp_avg_sq, float *const *targets,

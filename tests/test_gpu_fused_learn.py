@@ -419,8 +419,8 @@ def test_policy_image_packed_by_learns_second_launch(gpu_device):
 @pytest.mark.parametrize("images", [True, False])
 def test_actor_tail_in_one_launch_equals_the_two_launches(gpu_device, images):
     """tt_mlp_actor_tail: Q(s, mu(s)) / dQ/da through the updated critic and the actor's weight gradients + Adam + soft update + image
-    patches in ONE grid -- dQ/da handed from the row workgroups to the weight-gradient workgroups in device memory (agent-scope
-    atomics, one epoch word per row workgroup) -- against the same two launches apart: every weight, both targets, the Adam
+    patches in ONE grid -- dQ/da handed from the row workgroups to the weight-gradient workgroups in device memory (per row ONE
+    agent-scope atomic word {learn step, value}) -- against the same two launches apart: every weight, both targets, the Adam
     moments, the flat gradients and q / dQ/da after 4 learn() calls on fixture F5's batch, bit for bit; also as a replayed hipGraph;
     the give-up word stays clear; a step counter set back (resume) does not match stale epoch words."""
     import torch
@@ -452,7 +452,11 @@ def test_actor_tail_in_one_launch_equals_the_two_launches(gpu_device, images):
         torch.cuda.synchronize()
         assert fl.tail_gave_up() == 0 and int(fl.step_dev.item()) == 4
         if tail:
-            assert fl.tail_words[:16].cpu().tolist() == [4] * 16 and fl.tail_words[16:].eq(-1).all()
+            tw = fl.tail_words.cpu()
+            assert tw[:16].tolist() == [4] * 16 and tw[16:64].eq(-1).all()               # the row workgroups' hints
+            rows = tw[64:64 + 512].view(256, 2)                                            # per row {float bits of dQ/da, learn step}
+            assert rows[:, 1].eq(4).all() and torch.equal(rows[:, 0].contiguous().view(torch.float32), fl.dq_da.cpu())
+            assert tw[64 + 512:].eq(-1).all()
         flat = torch.cat([p.detach().reshape(-1) for net in agent._nets() for p in net.parameters()])
         outs.append((flat.clone(), fl.actor.m.clone(), fl.actor.v.clone(), fl.critic.m.clone(), fl.actor.flat_grad.clone(),
                      fl.q_pi.clone(), fl.dq_da.clone()))

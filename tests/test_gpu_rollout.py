@@ -533,6 +533,38 @@ def test_a_launch_that_really_gives_up_reaches_the_host(gpu_device, monkeypatch)
     env.close()
 
 
+def test_loop_with_learn_in_three_launches_equals_five(gpu_device, monkeypatch):
+    """Where learn() bounds the step (N <= 16384, or several updates per step) the loop runs learn() as three launches -- the forward
+    (+ the step tick), tt_mlp_critic_mid, tt_mlp_actor_tail: per-row gradients and dQ/da handed over in device memory inside a grid --
+    instead of five.  Same loop, TT_ACTOR_TAIL=0 / 1: every weight, the ring, the env state, the OU state after 4 + 20 + 4 + 1 + 6
+    steps (eager warm-up, graphs of 20 / 4 / 1, sampled draws, the image pack as a rider), bit for bit; also with 3 updates per step."""
+    import torch
+    from ddpg_trucktrailer_amd.rollout import DDPGRollout
+    from ddpg_trucktrailer_amd.vec_env import TruckTrailerVecEnv
+    for updates in (1, 3):
+        outs = []
+        for tail in ("0", "1"):
+            monkeypatch.setenv("TT_ACTOR_TAIL", tail)
+            env = TruckTrailerVecEnv(2048)
+            env.reset(seed=11)
+            loop = DDPGRollout(env, batch_size=256, replay_slots=16, seed=11, graph_steps=20, updates_per_step=updates)
+            assert loop.learner.fuse_tail == (tail == "1")
+            loop.run(4 + 20 + 4 + 1 + 6)
+            torch.cuda.synchronize()
+            assert loop.handover_gave_up == [] and loop.learner.tail_gave_up() == 0
+            outs.append((_loop_flat(loop).clone(), loop.ring.obs.clone(), loop.ring.act.clone(), loop.ring.rew.clone(), loop.env.state.clone(),
+                         loop.noise.x.clone(), loop.learner.actor.m.clone(), loop.learner.critic.v.clone()))
+            env.close()
+            del loop
+        for x, y in zip(*outs):
+            assert torch.equal(x, y), updates
+        assert torch.isfinite(outs[0][0]).all()
+    monkeypatch.delenv("TT_ACTOR_TAIL")
+    env = TruckTrailerVecEnv(1024); env.reset(seed=1)
+    assert DDPGRollout(env, batch_size=256, replay_slots=16, seed=1, graph_steps=4).learner.fuse_tail is True           # N <= 16384
+    env.close()
+
+
 def test_policy_edge_follows_the_grid_cap(gpu_device, monkeypatch):
     """A policy grid that is not capped below the CU count fills the chip (one workgroup per CU: 155 KB of LDS), and a launch
     spinning there for its image would keep the learn chain that makes the image off the GPU: such loops use graph edges."""
