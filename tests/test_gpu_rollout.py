@@ -533,10 +533,10 @@ def test_a_launch_that_really_gives_up_reaches_the_host(gpu_device, monkeypatch)
     env.close()
 
 
-def test_loop_with_learn_in_three_launches_equals_five(gpu_device, monkeypatch):
-    """Where learn() bounds the step (N <= 16384, or several updates per step) the loop runs learn() as three launches -- the forward
-    (+ the step tick), tt_mlp_critic_mid, tt_mlp_actor_tail: per-row gradients and dQ/da handed over in device memory inside a grid --
-    instead of five.  Same loop, TT_ACTOR_TAIL=0 / 1: every weight, the ring, the env state, the OU state after 4 + 20 + 4 + 1 + 6
+def test_loop_with_the_actor_tail_in_one_launch(gpu_device, monkeypatch):
+    """Where learn() bounds the step (N <= 16384, or several updates per step) the loop runs learn()'s last two launches as one grid
+    (tt_mlp_actor_tail: dQ/da handed over in device memory inside the grid): four launches instead of five.  Same loop,
+    TT_ACTOR_TAIL=0 / 1: every weight, the ring, the env state, the OU state after 4 + 20 + 4 + 1 + 6
     steps (eager warm-up, graphs of 20 / 4 / 1, sampled draws, the image pack as a rider), bit for bit; also with 3 updates per step."""
     import torch
     from ddpg_trucktrailer_amd.rollout import DDPGRollout
