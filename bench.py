@@ -641,14 +641,31 @@ def main():
             out["config"]["policy_image_handover"] += " (fallback: a launch gave up waiting during setup)"
     if ar_us is not None:
         out["allreduce_us"] = ar_us
+    if world > 1 and ddpg_loop is not None:
+        # data-parallel ranks must hold the SAME weights after every update (gradients averaged at both optimizer sites, rank-ordered
+        # sums in the peer-to-peer exchange): compared here, after the timed region -- a run whose ranks drifted apart is not a
+        # data-parallel run, whatever its throughput
+        flat = torch.cat([p.detach().reshape(-1) for net in ddpg_loop.agent._nets() for p in net.parameters()])
+        h = torch.stack([flat.view(torch.int32).to(torch.int64).sum(), (flat.view(torch.int32).to(torch.int64) * torch.arange(
+            1, flat.numel() + 1, device=dev, dtype=torch.int64)).sum()]).cpu()
+        hs = [torch.zeros_like(h) for _ in range(world)]
+        dist.all_gather(hs, h if dist.get_backend() != "nccl" else h.to(dev))
+        same = all(torch.equal(hs[0].cpu(), x.cpu()) for x in hs[1:]) and bool(torch.isfinite(flat).all())
+        out["config"]["dp_mode"]["ranks_hold_the_same_weights"] = same
+        if not same:
+            print(f"bench.py: rank {rank}: the ranks' weights differ after the run (checksums {[x.tolist() for x in hs]}): the gradient "
+                  "exchange is broken on this node", file=sys.stderr, flush=True)
     if rank == 0:
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     wd.enter("shutdown")
+    diverged = world > 1 and ddpg_loop is not None and not out["config"]["dp_mode"].get("ranks_hold_the_same_weights", True)
     if world > 1:
         dist.destroy_process_group()
     wd.stop()
+    if diverged:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

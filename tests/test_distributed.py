@@ -476,6 +476,7 @@ def test_bench_two_ranks_p2p_rehearsal_on_one_gpu(gpu_device):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["n_envs_total"] == 8192 and d["scaling"] == "weak"
     assert d["config"]["dp_mode"]["agreed_by_all_ranks"] == "p2p" and "no collective" in d["config"]["launch"]
+    assert d["config"]["dp_mode"]["ranks_hold_the_same_weights"] is True
     assert d["value"] == pytest.approx(8192 * 40 / (d["ms_per_step"] * 1e-3 * 40), rel=1e-9)
     assert "allreduce_us" in d
 
@@ -503,7 +504,7 @@ def test_p2p_exchange_probe_and_auto_mode_on_one_gpu(gpu_device):
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["dp_mode"] == {"asked": "auto", "decided_by": "probe (p2p exchange)", "this_rank_vote": True,
-                                                           "agreed_by_all_ranks": "p2p"}
+                                                           "agreed_by_all_ranks": "p2p", "ranks_hold_the_same_weights": True}
 
 
 def test_bench_refuses_fewer_gpus_than_ranks():
