@@ -256,8 +256,8 @@ class FusedLearner:
         (no process group needed) runs the same launches against this rank's own block.  Call before anything is captured."""
         import os
         import torch.distributed as dist
-        if timeout_s is None and os.environ.get("TT_P2P_TIMEOUT_S"):
-            timeout_s = float(os.environ["TT_P2P_TIMEOUT_S"])
+        if timeout_s is None:      # (default here: 10 s -- the first launches of a process load its kernels, and the ranks do that at
+            timeout_s = float(os.environ.get("TT_P2P_TIMEOUT_S", "10"))      # their own pace; the library's own default is 2 s)
         have = dist.is_available() and dist.is_initialized()
         world, rank = (dist.get_world_size(group), dist.get_rank(group)) if have else (1, 0)
         if world > L.P2P_MAX_RANKS:
