@@ -31,7 +31,9 @@ def build(force=False, verbose=False, defines=(), out=None):
     if out is None and not force and not stale():
         return LIB
     out = out or LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # kernarg preload: the first 16 dwords of a kernel's leading scalar / pointer arguments reach the wave in SGPRs instead of through
+    # its first s_load round trip (the hot kernels put the pointers of their first loads there: csrc/ttlearn.hip, KernargWarm)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-kernarg-preload-count=16",
            "-I" + os.path.join(ROOT, "include"), "-o", out] + ["-D" + d for d in defines] + SRC
     if verbose:
         print(" ".join(cmd))

@@ -91,6 +91,8 @@ __device__ unsigned long long g_stamps[32];
 __device__ unsigned long long g_blk[512][2];
 #define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_stamps[i] = wall_clock64(); g_stamps[16 + i] = clock64(); } } while (0)
 #define STAMPB(i, blk0) do { if ((int)blockIdx.x == (blk0) && threadIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+__device__ unsigned long long g_sub[16];        // finer stamps inside the row forward's phases (workgroup 0; tools/learn_blocks.py)
+#define SUB(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sub[i] = wall_clock64(); } while (0)
 __device__ unsigned long long g_wst[2][16];     // phase stamps of workgroup 0 of k_bwd_weights<critic / actor>
 #define WST(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_wst[ROWSCALE ? 1 : 0][i] = wall_clock64(); } while (0)
 // begin / end of every workgroup of learn()'s launches: [kernel][block][2] (tools/learn_blocks.py)
@@ -102,6 +104,7 @@ __device__ TTLog g_log_learn[5];
 #else
 #define STAMP(i) do { } while (0)
 #define STAMPB(i, blk0) do { } while (0)
+#define SUB(i) do { } while (0)
 #define KBEGIN(k) do { } while (0)
 #define KEND(k) do { } while (0)
 #define WST(i) do { } while (0)
@@ -137,6 +140,30 @@ __device__ __forceinline__ void kernarg_warm() {
     for (int i = 0; i < LINES; ++i) asm volatile("" ::"s"(t[i]));      // (the destinations stay allocated until the loads are back)
 #endif
 }
+// The same in two halves, for kernels whose FIRST loads go through pointers that are leading scalar kernel arguments: those
+// arrive in SGPRs with the wave (kernarg preload, -mllvm -amdgpu-kernarg-preload-count=16 in build.py: up to 16 dwords of leading
+// non-struct arguments), so the loads can leave while the rest of the segment is still on its way -- issue(), the first loads,
+// wait().  (A struct argument ends the preloaded prefix: pointers inside Weights / Saved / ... never are.)
+template <int BYTES>
+struct KernargWarm {
+    static constexpr int LINES = (BYTES + 63) / 64;
+    unsigned t[LINES];
+    __device__ __forceinline__ void issue() {
+#ifndef TT_DBG_NO_KERNARG_WARM
+        kernarg_touch_all<0, LINES>((const void *)__builtin_amdgcn_kernarg_segment_ptr(), t);
+#endif
+    }
+    __device__ __forceinline__ void wait() {
+#ifndef TT_DBG_NO_KERNARG_WARM
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < LINES; ++i) asm volatile("" ::"s"(t[i]));
+#endif
+    }
+};
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
 
 // __restrict__ on the members: none of these buffers alias, and without it every store (saved activations,
 // gradients) pins the loads that follow it in program order
@@ -260,7 +287,10 @@ __device__ __forceinline__ void split4(const float4 x, uint2 &ph, uint2 &pm) {
 // enters after LayerNorm2 (networks.py:62-66).
 // waves_per_eu(1,1): tell the scheduler NOT to trade the deep load pipelining for occupancy it cannot use anyway
 // (16 workgroups on 256 CUs); without it hipcc keeps ~60 VGPRs and issues the weight loads a few at a time
-template <bool CRITIC>
+struct EarlyW {
+    const float *__restrict__ w1, *__restrict__ b1, *__restrict__ g1, *__restrict__ be1;
+};
+template <bool CRITIC, class Hook = NoHook>
 __device__ __forceinline__ void fwd_small_body(const int n, const float *__restrict__ obs,
                                                const float *__restrict__ action, const Weights &W,
                                                float *__restrict__ out, const Saved &sv, float *__restrict__ dq_da,
@@ -269,7 +299,11 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
                                                const float *__restrict__ obs_row_lane = nullptr,
                                                const bool act_given = false, const float act_row0 = 0.f,
                                                const float act_row1 = 0.f, unsigned long long *dq_words = nullptr,
-                                               const unsigned dq_epoch = 0u) {
+                                               const unsigned dq_epoch = 0u, const EarlyW *early = nullptr,
+                                               const Hook &loads_issued = Hook()) {
+    // early (optional): fc1 and the layer-1 vectors through pointers that reached the wave in SGPRs (leading kernel arguments) --
+    // the same addresses as W's; loads_issued(): called once this phase's loads are out (the kernel's wait for the rest of its arguments)
+    const EarlyW E = early ? *early : EarlyW{W.w1, W.b1, W.g1, W.be1};
     // obs_row_lane (optional): this lane's observation row for layer 1 (row row0 + (lane & 15)) when the rows are gathered
     // from a replay ring instead of read from obs [n,23]; act_given / act_row0, 1: the actions of this wave's two rows likewise.
     // h1_s [16][404]: fc1 pre-activations, then the A operand of layer 2; z_s [16][308]: fc2 pre-activations.
@@ -291,8 +325,8 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
 #pragma unroll
     for (int i = 0; i < RV; ++i) {
         const int c = rv_col(lane, i), cc = c < H1 ? c : 0;       // (values beyond column 399 are never used)
-        pb1[i] = *reinterpret_cast<const float4 *>(W.b1 + cc); pg1[i] = *reinterpret_cast<const float4 *>(W.g1 + cc);
-        pbe1[i] = *reinterpret_cast<const float4 *>(W.be1 + cc);
+        pb1[i] = *reinterpret_cast<const float4 *>(E.b1 + cc); pg1[i] = *reinterpret_cast<const float4 *>(E.g1 + cc);
+        pbe1[i] = *reinterpret_cast<const float4 *>(E.be1 + cc);
     }
     // ---- layer 1 (K = 23): operands straight from global; this wave's column tiles t = wave, wave+NW, ...
     f32x4 acc1[MT1];
@@ -313,29 +347,37 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
         constexpr int W1_F4 = H1 * IN / 4, W1_PER = (W1_F4 + 64 * NW - 1) / (64 * NW);
         float4 wv[W1_PER];
 #pragma unroll
-        for (int q = 0; q < W1_PER; ++q) wv[q] = f4_ldu(W.w1 + 4 * min(tid + 64 * NW * q, W1_F4 - 1));
+        for (int q = 0; q < W1_PER; ++q) wv[q] = f4_ldu(E.w1 + 4 * min(tid + 64 * NW * q, W1_F4 - 1));
 #pragma unroll
         for (int ks = 0; ks < INP / 4; ++ks) a[ks] = arow[min(ks * 4 + l4, IN - 1)];
+        loads_issued();
+        SUB(0);
 #pragma unroll
         for (int q = 0; q < W1_PER; ++q)
             if (tid + 64 * NW * q < W1_F4) *reinterpret_cast<float4 *>(w1_s + 4 * (tid + 64 * NW * q)) = wv[q];
+        SUB(1);
         lds_barrier();
+        SUB(2);
 #pragma unroll
         for (int ks = 0; ks < INP / 4; ++ks) a[ks] = (ks * 4 + l4 < IN && arow_ok) ? a[ks] : 0.f;
+        // every fragment of the wave's tiles first (24 LDS reads in flight together), then the products k-step by k-step ACROSS the
+        // tiles: six MFMAs into one accumulator in a row wait for each other (a dependent 16x16x4 issues every ~40 cycles, an
+        // independent one every 32), tile by tile that was the order
+        float b[MT1][INP / 4];
 #pragma unroll
         for (int i = 0; i < MT1; ++i) {
-            if (wave + NW * i < NT1) {
-                const float *wr = w1_s + ((wave + NW * i) * 16 + l15) * IN;
-                float b[INP / 4];
+            const float *wr = w1_s + (min(wave + NW * i, NT1 - 1) * 16 + l15) * IN;
 #pragma unroll
-                for (int ks = 0; ks < INP / 4; ++ks) {
-                    const float v = wr[min(ks * 4 + l4, IN - 1)];
-                    b[ks] = ks * 4 + l4 < IN ? v : 0.f;          // (only k = 23, the padding of the last k4 group, is not)
-                }
-#pragma unroll
-                for (int ks = 0; ks < INP / 4; ++ks) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b[ks], acc1[i], 0, 0, 0);
+            for (int ks = 0; ks < INP / 4; ++ks) {
+                const float v = wr[min(ks * 4 + l4, IN - 1)];
+                b[i][ks] = ks * 4 + l4 < IN ? v : 0.f;          // (only k = 23, the padding of the last k4 group, is not)
             }
         }
+#pragma unroll
+        for (int ks = 0; ks < INP / 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < MT1; ++i)
+                if (wave + NW * i < NT1) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b[i][ks], acc1[i], 0, 0, 0);
         // The first group of fc2 fragments (three k32 steps of this wave's tiles, straight from L2) is requested HERE: it does not
         // depend on the activations, and requested where layer 2 starts it cost that phase one exposed round trip.  (Requested
         // in front of layer 1 it delays the other waves' layer-1 operands: 144 KB through the same address pipe.)
@@ -360,7 +402,9 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
             for (int r = 0; r < 4; ++r) h1_s[(l4 * 4 + r) * HS1 + t * 16 + l15] = acc1[i][r];
         }
     }
+    SUB(3);
     lds_barrier();
+    SUB(4);
     // bias, LayerNorm(400) (biased variance, eps 1e-5), ReLU for this wave's two rows.  With an fc2 image the rows leave as
     // the two f16 planes of the layer-2 operand, which share the buffer with the f32 tile: every wave has read its rows
     // before any plane is written
@@ -378,6 +422,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
         }
     }
     if (img) lds_barrier();
+    SUB(5);
 #pragma unroll
     for (int rr = 0; rr < TR / NW; ++rr) {
         const int lr = wave * (TR / NW) + rr, row = row0 + lr;
@@ -420,6 +465,7 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
             }
         }
     }
+    SUB(6);
     lds_barrier();   // the 16 x 400 activation tile is complete
     STAMP(2);
     // layer 2's per-column vectors: requested behind the LAST group of fc2 fragments (the prefetch registers are free by then),
@@ -631,15 +677,22 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
 
 template <bool CRITIC>
 __global__ __launch_bounds__(64 * NW) void k_fwd_small(const int n, const float *__restrict__ obs,
-                                                   const float *__restrict__ action, const Weights W,
+                                                   const float *__restrict__ action, const float *__restrict__ w1e,
+                                                   const float *__restrict__ b1e, const float *__restrict__ g1e,
+                                                   const float *__restrict__ be1e, const Weights W,
                                                    float *__restrict__ out, const Saved sv, float *__restrict__ dq_da,
                                                    float *__restrict__ z_state) {
+    // (n .. be1e: 14 dwords of leading scalar arguments = the preloaded prefix; w1e .. be1e repeat W.w1, b1, g1, be1)
     __shared__ __attribute__((aligned(16))) float h1_s[H1S_FLOATS];
     __shared__ __attribute__((aligned(16))) float z_s[TR * DS];
     __shared__ __attribute__((aligned(16))) float w1_s[H1 * IN];
-    kernarg_warm<8 + 16 + (int)sizeof(Weights) + 8 + (int)sizeof(Saved) + 16>();
+    KernargWarm<64 + (int)sizeof(Weights) + 8 + (int)sizeof(Saved) + 16> warm;
+    warm.issue();
     KBEGIN(3);
-    fwd_small_body<CRITIC>(n, obs, action, W, out, sv, dq_da, z_state, h1_s, z_s, w1_s, blockIdx.x * TR);
+    const EarlyW E{w1e, b1e, g1e, be1e};
+    auto hook = [&]() __attribute__((always_inline)) { warm.wait(); };
+    fwd_small_body<CRITIC, decltype(hook)>(n, obs, action, W, out, sv, dq_da, z_state, h1_s, z_s, w1_s, blockIdx.x * TR, nullptr, false, 0.f,
+                                           0.f, nullptr, 0u, &E, hook);
     KEND(3);
 }
 
@@ -1942,10 +1995,10 @@ int tt_mlp_forward_save(int n, int critic, const float *obs, const float *action
     }
     const dim3 grid((n + TR - 1) / TR), block(64 * NW);
     if (critic)
-        hipLaunchKernelGGL(k_fwd_small<true>, grid, block, 0, stream, n, obs, action, to_weights(w), out, sv, dq_da,
+        hipLaunchKernelGGL(k_fwd_small<true>, grid, block, 0, stream, n, obs, action, w->w1, w->b1, w->g1, w->be1, to_weights(w), out, sv, dq_da,
                            static_cast<float *>(nullptr));
     else
-        hipLaunchKernelGGL(k_fwd_small<false>, grid, block, 0, stream, n, obs, action, to_weights(w), out, sv,
+        hipLaunchKernelGGL(k_fwd_small<false>, grid, block, 0, stream, n, obs, action, w->w1, w->b1, w->g1, w->be1, to_weights(w), out, sv,
                            static_cast<float *>(nullptr), static_cast<float *>(nullptr));
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
@@ -2004,7 +2057,7 @@ int tt_critic_state_forward(int n, const float *obs, const tt_mlp_weights *w, fl
     if (n == 0) return TT_OK;
     const Saved sv{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k_fwd_small<true>, dim3((n + TR - 1) / TR), dim3(64 * NW), 0, stream, n, obs,
-                       static_cast<const float *>(nullptr), to_weights(w), static_cast<float *>(nullptr), sv,
+                       static_cast<const float *>(nullptr), w->w1, w->b1, w->g1, w->be1, to_weights(w), static_cast<float *>(nullptr), sv,
                        static_cast<float *>(nullptr), z_state);
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }
@@ -2292,6 +2345,9 @@ int tt_debug_log_learn(int k, unsigned long long *out, int reset) {
 }
 int tt_debug_learn_poll(unsigned long long *out4) {
     return hipMemcpyFromSymbol(out4, HIP_SYMBOL(ttnet::g_poll), sizeof(unsigned long long) * 4) == hipSuccess ? 0 : -3;
+}
+int tt_debug_substamps(unsigned long long *out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sub), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -3;
 }
 int tt_debug_stamps(unsigned long long *out32) {
     return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -3;

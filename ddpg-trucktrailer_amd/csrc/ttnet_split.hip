@@ -93,11 +93,15 @@ __device__ __forceinline__ uint4 lds_frag(const LdsBases &L, const int off) {   
 // the PREVIOUS tile's epilogue and land behind it; the per-neuron vectors stay in LDS.
 template <bool CRITIC>
 __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int tile0, const int tile_end,
+                                                      int *__restrict__ cursor_e, const long long *__restrict__ step_e,
                                                       const float *__restrict__ obs,
-                                                      const float *__restrict__ action,
                                                       const unsigned char *__restrict__ ws,
-                                                      const unsigned char *__restrict__ ws_alt, float *__restrict__ out,
+                                                      const unsigned char *__restrict__ ws_alt,
+                                                      const float *__restrict__ action, float *__restrict__ out,
                                                       const ActArgs act) {
+    // The first 16 dwords of the arguments reach the wave in SGPRs (kernarg preload, build.py): n .. action.  cursor_e / step_e
+    // repeat act.cursor / act.step_dev there, so that the launch's first loads -- the step counter and the image epochs --
+    // leave before the rest of the argument segment (the struct) has been fetched.
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const float *p1_s = reinterpret_cast<const float *>(lds_raw + RING_BYTES);              // g1' | be1'       [2][416]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -121,8 +125,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
     // (that of the step's parity: the other one may be being written for the next step) comes from the opening pack launch,
     // which need not be ordered before this launch: await_image (ttnet_common.h) -- behind the first tile's observation loads,
     // which do not depend on it.
-    const EpochPair epochs = await_image_early(act.cursor);      // (requested beside the step counter, not behind it)
-    const long long kstep = act.cursor ? *act.step_dev : 0;
+    const EpochPair epochs = await_image_early(cursor_e);        // (requested beside the step counter, not behind it)
+    const long long kstep = cursor_e ? *step_e : 0;
     const bool odd = act.cursor && (kstep & 1);
     const bool local = act.cursor && act.ring_slots > 0;
     const int slot_t = local ? (int)(kstep % act.ring_slots) : 0;
@@ -583,15 +587,15 @@ static int launch_split(int n, const float *obs, const float *action, const tt_m
         capped = ntiles;
         if (w->capped_grids > 0 && (long long)w->capped_grids * limit < ntiles) capped = w->capped_grids * limit;
         const int rounds = (capped + limit - 1) / limit, g = (capped + rounds - 1) / rounds;
-        hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(g), dim3(256), LDS_BYTES, stream, n, 0, capped, obs, action,
+        hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(g), dim3(256), LDS_BYTES, stream, n, 0, capped, act.cursor, act.step_dev, obs,
                            reinterpret_cast<const unsigned char *>(w->split_ws),
-                           reinterpret_cast<const unsigned char *>(w->split_ws_alt), out, act);
+                           reinterpret_cast<const unsigned char *>(w->split_ws_alt), action, out, act);
     }
     if (capped < ntiles) {
         const int rest = ntiles - capped, rounds = (rest + chip - 1) / chip, g = (rest + rounds - 1) / rounds;
-        hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(g), dim3(256), LDS_BYTES, stream, n, capped, ntiles, obs, action,
+        hipLaunchKernelGGL((k_mlp_split<CRITIC>), dim3(g), dim3(256), LDS_BYTES, stream, n, capped, ntiles, act.cursor, act.step_dev, obs,
                            reinterpret_cast<const unsigned char *>(w->split_ws),
-                           reinterpret_cast<const unsigned char *>(w->split_ws_alt), out, act);
+                           reinterpret_cast<const unsigned char *>(w->split_ws_alt), action, out, act);
     }
     return hipGetLastError() == hipSuccess ? TT_OK : TT_EHIP;
 }

@@ -41,6 +41,15 @@ def phases(lib):
     f = list(st)
     print("  row kernels, workgroup 0 (us): fwd layer1 %.2f LN1 %.2f layer2 %.2f epilogue %.2f | bwd phaseA %.2f phaseB %.2f phaseC %.2f" % (
         tuple((f[i + 1] - f[i]) / 100 for i in range(4)) + tuple((f[i + 1] - f[i]) / 100 for i in (8, 9, 10))))
+    if hasattr(lib, "tt_debug_substamps"):
+        sb = (C.c_ulonglong * 16)()
+        lib.tt_debug_substamps(sb)
+        g = list(sb)
+        us = lambda a, b: (b - a) / 100
+        print("  row forward, workgroup 0, inside the phases (us): entry -> layer-1 loads issued %.2f, fc1 into LDS (= loads landed) %.2f, barrier %.2f, "
+              "products %.2f | accumulators into LDS %.2f, barrier %.2f, rows read (+ barrier) %.2f, statistics + normalise + split + saves issued %.2f, "
+              "barrier %.2f" % (us(f[0], g[0]), us(g[0], g[1]), us(g[1], g[2]), us(g[2], f[1]), us(f[1], g[3]), us(g[3], g[4]), us(g[4], g[5]),
+                                us(g[5], g[6]), us(g[6], f[2])))
 
 
 def report(a, title, lib=None):
