@@ -1716,8 +1716,9 @@ __device__ __forceinline__ void bwd_weights_body(const int blk, const int n, con
     KEND(ROWSCALE ? 4 : 2);
 }
 
+// (three workgroups per CU: beside the policy's grid ~85 CUs are free for the ~205 of this launch -- 168 registers, see above)
 template <bool ROWSCALE>
-__global__ __launch_bounds__(256) void k_bwd_weights(const int n, const int critic, const float *__restrict__ obs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_bwd_weights(const int n, const int critic, const float *__restrict__ obs,
                                                      const float *__restrict__ action, const Saved sv,
                                                      const BwdOut d, const Grads G, const AdamFused A, const RowScale RS) {
     __shared__ __attribute__((aligned(16))) float part[4][4][256];     // [wave][tile][lane*4 + r]

@@ -288,6 +288,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
         // LayerNorm(400) (biased variance, eps 1e-5) on the SCALED pre-activations: mean and deviations scale with them,
         // 1/sigma absorbs the scale; then gamma*SX, beta*SX and ReLU give the layer-2 operand already scaled by SX.
         // Tile 12 holds neurons 384..399 in v < 8.
+        // Only the two statistics passes stand between the layers.  The third pass -- normalise, ReLU, split into the two f16
+        // pieces layer 2 multiplies with -- needs nothing but mean and 1/sigma and produces the B operand of ONE k16 step from
+        // 16 accumulator registers, so it runs INSIDE layer 2 (round 4), two steps ahead of the step that multiplies with it, in
+        // the issue slots the matrix pipe leaves free (ln_chunk below).  hb[s] / mb[s] are the B fragments (h, m planes) of k16
+        // step s -- element j of lane half h is neuron 16 s + 8 (j >> 2) + 4 h + (j & 3), i.e. registers 8 (s & 1) .. + 7 of tile
+        // s >> 1, the order the packed fc2 fragments are laid out in.
+        f32x2 nmean, rstdp;
         {
             f32x2 sp = pk(0.f, 0.f);
 #pragma unroll
@@ -297,51 +304,49 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
                     sp += pk(acc1[t][v], acc1[t][v + 1]) + pk(acc1[t][v + 2], acc1[t][v + 3]);
             const float s = sp[0] + sp[1];
             const float mean = (s + __shfl_xor(s, 32)) * (1.f / H1);
-            const f32x2 nmean = pk(-mean, -mean);
+            nmean = pk(-mean, -mean);
             f32x2 ssp = pk(0.f, 0.f);
 #pragma unroll
             for (int t = 0; t < T1; ++t)
 #pragma unroll
                 for (int v = 0; v < (t == T1 - 1 ? 8 : 16); v += 2) {
-                    const f32x2 d = pk(acc1[t][v], acc1[t][v + 1]) + nmean;
-                    acc1[t][v] = d[0]; acc1[t][v + 1] = d[1];
+                    const f32x2 d = pk(acc1[t][v], acc1[t][v + 1]) + nmean;   // (formed again where it is used: same operation, same bits)
                     ssp = pk_fma(d, d, ssp);
                 }
             const float ss = ssp[0] + ssp[1];
             const float var = (ss + __shfl_xor(ss, 32)) * (1.f / H1) * (UNSCALE * UNSCALE);
             const float rstd = rsqrtf(var + 1e-5f) * UNSCALE;
-            const f32x2 rstdp = pk(rstd, rstd);
-            // gamma*SX, beta*SX, ReLU, then straight into the two f16 pieces layer 2 multiplies with: hb[s] / mb[s] are the
-            // B fragments (h, m planes) of k16 step s -- element j of lane half h is neuron 16 s + 8 (j >> 2) + 4 h + (j & 3),
-            // i.e. registers 8 (s & 1) .. + 7 of tile s >> 1, the order the packed fc2 fragments are laid out in
-            // The per-neuron vectors come from LDS a whole tile AHEAD of their use (8 ds_read_b128, pinned above the tile's
-            // arithmetic): a lone wave hides no latency, and read-then-use cost one exposed LDS round trip per group of four.
-            float4 gq[2][4], bq[2][4];
-            auto ld1 = [&](const int t, float4 (&g)[4], float4 (&be)[4]) {
-#pragma unroll
-                for (int i = 0; i < (t == T1 - 1 ? 2 : 4); ++i) {
-                    g[i] = lds4(pv1 + 32 * t + 8 * i);
-                    be[i] = lds4(pv1 + H1P + 32 * t + 8 * i);
-                }
-            };
-            ld1(0, gq[0], bq[0]);
-#pragma unroll
-            for (int t = 0; t < T1; ++t) {
-                if (t + 1 < T1) ld1(t + 1, gq[(t + 1) & 1], bq[(t + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < (t == T1 - 1 ? 2 : 4); ++i) {
-                    const float4 g = gq[t & 1][i], be = bq[t & 1][i];
-                    const f32x2 ya = pk_fma(pk(acc1[t][4 * i], acc1[t][4 * i + 1]) * rstdp, pk(g.x, g.y), pk(be.x, be.y));
-                    const f32x2 yb = pk_fma(pk(acc1[t][4 * i + 2], acc1[t][4 * i + 3]) * rstdp, pk(g.z, g.w), pk(be.z, be.w));
-                    const float y0 = fmaxf(ya[0], 0.f), y1 = fmaxf(ya[1], 0.f), y2 = fmaxf(yb[0], 0.f), y3 = fmaxf(yb[1], 0.f);
-                    const int st = 2 * t + (i >> 1), e = 2 * (i & 1);         // k16 step, first of its two packed registers
-                    split2(y0, y1, hb[st][e], mb[st][e]);
-                    split2(y2, y3, hb[st][e + 1], mb[st][e + 1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            rstdp = pk(rstd, rstd);
         }
+        // One GROUP = four neurons of this lane (registers 4i .. 4i+3 of tile t; group number G = 4t + i = 2 * step + half), in
+        // five chunks of 3-4 vector instructions; a chunk fits in the shadow of one MFMA.  gamma/beta of group G + 1 are read
+        // from LDS in chunk 2 of group G (three tiles of MFMAs before their use).
+        constexpr int GROUPS = 2 * STEPS;                                     // 50: tile 12 has groups 48, 49 only
+        float4 gq[2], bq[2];
+        f32x2 ya, yb;
+        float y0, y1, y2, y3;
+        auto ln_read = [&](const int G) __attribute__((always_inline)) {
+            gq[G & 1] = lds4(pv1 + 8 * G);                                    // 32 t + 8 i
+            bq[G & 1] = lds4(pv1 + H1P + 8 * G);
+        };
+        auto ln_chunk = [&](const int G, const int k) __attribute__((always_inline)) {
+            const int t = G >> 2, i = G & 3, st = G >> 1, e = 2 * (G & 1);
+            const float4 g = gq[G & 1], be = bq[G & 1];
+            if (k == 0) ya = pk_fma((pk(acc1[t][4 * i], acc1[t][4 * i + 1]) + nmean) * rstdp, pk(g.x, g.y), pk(be.x, be.y));
+            if (k == 1) yb = pk_fma((pk(acc1[t][4 * i + 2], acc1[t][4 * i + 3]) + nmean) * rstdp, pk(g.z, g.w), pk(be.z, be.w));
+            if (k == 2) {
+                y0 = fmaxf(ya[0], 0.f); y1 = fmaxf(ya[1], 0.f); y2 = fmaxf(yb[0], 0.f); y3 = fmaxf(yb[1], 0.f);
+                if (G + 1 < GROUPS) ln_read(G + 1);
+            }
+            if (k == 3) split2(y0, y1, hb[st][e], mb[st][e]);
+            if (k == 4) split2(y2, y3, hb[st][e + 1], mb[st][e + 1]);
+        };
+        // steps 0 and 1 (groups 0..3) before the first MFMA
+        ln_read(0);
+#pragma unroll
+        for (int G = 0; G < 4; ++G)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) ln_chunk(G, k);
 
         if (first) NSTAMP(3);
         // ---- layer 2: 25 k16 steps x 10 neuron tiles x 3 f16 MFMAs; the h1 registers are the B operand
@@ -353,7 +358,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
         // Hand-pipelined issue order, pinned with sched_barrier(0) between every pair of instruction groups: each of the
         // three MFMAs of a tile is followed by one small job that issues while the matrix pipe is busy (an MFMA holds the
         // wave's issue port for 8 of its 32 cycles) -- the two fragment reads of the tile two ahead, and in tiles 5..9 one
-        // LDS-DMA piece of step s + 6.  No vector arithmetic is left in the loop: the B operand was split once, in LayerNorm 1.
+        // LDS-DMA piece of step s + 6 -- and, behind the first MFMA of every tile, one chunk of LayerNorm 1's last pass for the B
+        // operand of step s + 2 (a tenth of a step's worth: 3-4 vector instructions).
         // One barrier per step, in the middle (before tile 5): it publishes step s + 1 (every wave has waited for its own
         // pieces of it with a COUNTED vmcnt that leaves the four younger steps in flight) and tells that every wave is past
         // step s - 1, whose slot the DMA of step s + 6 overwrites.  Fragments are read TWO tiles ahead
@@ -393,6 +399,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_split(const int n, const int til
                 const int nx = u + 2 < T2 ? slot + (u + 2) * 2048 : nslot + (u + 2 - T2) * 2048;
                 acc2[u] = mfma_f16(c0h, vm, acc2[u]); SB;      // small terms first
                 if (more) c2h = lds_frag(LB, nx);
+                if (s + 2 < STEPS) ln_chunk(2 * (s + 2) + u / 5, u % 5);      // LayerNorm 1's last pass for step s + 2
                 SB;
                 acc2[u] = mfma_f16(c0m, vh, acc2[u]); SB;
                 if (more) c2m = lds_frag(LB, nx + 1024);

@@ -15,6 +15,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import learn_blocks
 import torch
 
 from ddpg_trucktrailer_amd import _lib as L
@@ -165,6 +167,8 @@ def main():
             prev = en.max()
         first = kb[0, :64, 0][kb[0, :64, 0] > 0].min()
         print(f"    learn chain, first start -> last end: {(prev - first) / 100.0:7.2f} us; it began {us(first):+.2f} us relative to the policy launch")
+        print("  the same launches' workgroup 0, phase by phase, as they ran IN the loop (tools/learn_blocks.py prints them for learn() alone):")
+        learn_blocks.phases(lib)
     lib.tt_debug_bstamps.argtypes = [C.c_void_p, C.c_int]
     for name in ("tt_debug_log_policy", "tt_debug_log_step", "tt_debug_log_learn"):
         getattr(lib, name).restype = C.c_int
