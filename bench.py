@@ -122,6 +122,21 @@ class _NoWatchdog:
         pass
 
 
+def weights_agree(loop, dev, world):
+    """(every rank holds the same finite weights, the ranks' checksums): a collective over the default process group."""
+    import torch
+    import torch.distributed as dist
+    flat = torch.cat([p.detach().reshape(-1) for net in loop.agent._nets() for p in net.parameters()])
+    h = torch.stack([flat.view(torch.int32).to(torch.int64).sum(), (flat.view(torch.int32).to(torch.int64) * torch.arange(
+        1, flat.numel() + 1, device=dev, dtype=torch.int64)).sum()]).cpu()
+    if dist.get_backend() == "nccl":      # (RCCL gathers device tensors only: every tensor of the call on this rank's GPU)
+        h = h.to(dev)
+    hs = [torch.zeros_like(h) for _ in range(world)]
+    dist.all_gather(hs, h)
+    same = all(torch.equal(hs[0].cpu(), x.cpu()) for x in hs[1:]) and bool(torch.isfinite(flat).all())
+    return same, hs
+
+
 def allreduce_us(dev, world, reps=50):
     """Wire + launch time of the two gradient all-reduces alone: `reps` eager AVG all-reduces of each site's flat f32 buffer,
     event-timed back to back after 5 untimed ones; max over ranks.  Lets a scaling curve be split into time on the wire and
@@ -432,40 +447,78 @@ def main():
         extra = {"graph_steps": graph_k}
     else:
         from ddpg_trucktrailer_amd.rollout import DDPGRollout
-        loop = DDPGRollout(env, batch_size=args.batch, replay_slots=args.replay_slots, seed=27 + rank,
-                           world_size=world, use_graph=not args.no_graph, fused_learn=not args.torch_learn,
-                           graph_steps=args.step_graph, updates_per_step=args.updates_per_step,
-                           pipeline=False if args.serial else None, graph_collectives=dp_graph,
-                           dp_exchange="p2p" if p2p else None, data_parallel=True if p2p else None)
-        wd.enter("prepare (eager steps + graph capture)")
-        loop.prepare()       # one-off work (4 untimed vector steps + graph capture) before warm-up and the timed region
-        wd.enter("first graph launches")
-        loop.first_launches()   # ... and the first launch of every captured graph (it uploads the graph)
-        torch.cuda.synchronize()
+
+        def build_ddpg(p2p, dp_graph):
+            """The loop with one gradient-exchange structure, prepared and launched once, + what the line says about it."""
+            loop = DDPGRollout(env, batch_size=args.batch, replay_slots=args.replay_slots, seed=27 + rank,
+                               world_size=world, use_graph=not args.no_graph, fused_learn=not args.torch_learn,
+                               graph_steps=args.step_graph, updates_per_step=args.updates_per_step,
+                               pipeline=False if args.serial else None, graph_collectives=dp_graph,
+                               dp_exchange="p2p" if p2p else None, data_parallel=True if p2p else None)
+            wd.enter("prepare (eager steps + graph capture)")
+            loop.prepare()       # one-off work (4 untimed vector steps + graph capture) before warm-up and the timed region
+            wd.enter("first graph launches")
+            loop.first_launches()   # ... and the first launch of every captured graph (it uploads the graph)
+            torch.cuda.synchronize()
+            workload = (f"{vname} N={n}/GPU + full DDPG learn() x{args.updates_per_step} per vector step (actor/critic 400x300, "
+                        f"batch {args.batch}, OU noise, replay ring {args.replay_slots}xN) (BASELINE config {5 if variant else 3})")
+            if loop.graph_steps:
+                launch = (f"every vector step a hipGraph replay: graphs of {loop.graph_steps}, 4 and 1 whole steps "
+                          f"serve every ring position (device cursor)" + ((" -- no collective: each rank's two Adam launches read the peers' gradient "
+                                                                    "buffers themselves (IPC-opened device memory, flag barrier)" if p2p else
+                                                                    " -- the two RCCL gradient all-reduces of a step are nodes of its graph")
+                                                                   if loop.dp else "") if not (loop.dp and not loop.dp_single_graph) else
+                          "three hipGraph segments per step with the two RCCL gradient all-reduces between them")
+            else:
+                launch = "eager, learn() as a hipGraph" if loop.use_graph else "eager"
+            order = ("pipelined: learn() of vector step t (batch from the steps up to t-2) runs beside the policy + env launches of "
+                     "steps t-1 and t on a second chain of the graph; the policy acts with the weights learn() of step t-1 left"
+                     if loop.pipeline else "serial: policy, env step, then learn() on a window that includes the new step")
+            extra = {"batch": args.batch, "updates_per_step": args.updates_per_step,
+                     "replay_capacity": args.replay_slots * n, "launch": launch, "order": order,
+                     "dp_mode": (None if not loop.dp else
+                                 {"asked": args.dp_mode, "decided_by": dp_asked, "this_rank_vote": bool(p2p_vote if p2p else dp_vote),
+                                  "agreed_by_all_ranks": "p2p" if p2p else ("graph" if loop.dp_single_graph else "segments")}),
+                     "env_steps_per_update": n / args.updates_per_step, "setup_vector_steps": loop.vector_steps,
+                     "note": ("throughput of the configuration BASELINE.json names; how the same loop trains at this and at other "
+                              "update ratios (--updates-per-step): profiles/r03_training_behaviour.md")}
+            return loop, workload, extra
+
+        loop, workload, extra = build_ddpg(p2p, dp_graph)
+        if p2p and world > 1 and args.dp_mode == "auto":
+            # The peer-to-peer exchange was CHOSEN by a probe (auto), never asked for: before anything is timed it has to carry the real
+            # loop on this node -- two graph lengths of steps, then no wait abandoned and the same weights on every rank.  If not, the
+            # run goes on with the RCCL all-reduces in three graph segments per step (the structure that needs nothing from the node
+            # but RCCL) and the line says so.  Every rank executes the same collectives here whatever happened to it locally.
+            wd.enter("p2p validation (steps through the exchange before it is trusted)")
+            ok_here, why = True, ""
+            try:
+                loop.run(2 * max(1, loop.graph_steps))
+                torch.cuda.synchronize()
+                if loop.learner.p2p_gave_up():
+                    ok_here, why = False, f"an exchange wait was abandoned at learn step {loop.learner.p2p_gave_up()}"
+            except RuntimeError as exc:
+                ok_here, why = False, str(exc)[:300]
+            if os.environ.get("TT_BENCH_TEST_P2P_FAIL") == str(rank):      # (tests/test_distributed.py: the fallback below must work)
+                ok_here, why = False, "TT_BENCH_TEST_P2P_FAIL"
+            from ddpg_trucktrailer_amd.dp_probe import agree
+            ok_all = agree(ok_here, dev)
+            same = weights_agree(loop, dev, world)[0] if ok_all else False       # (a collective: only when every rank gets here)
+            if not (ok_all and same):
+                print(f"bench.py: rank {rank}: the peer-to-peer exchange did not carry the loop on this node ({why or 'another rank' if not ok_all else 'the ranks differ'}); "
+                      "going on with RCCL all-reduces in three graph segments per step", file=sys.stderr, flush=True)
+                wd.enter("p2p fallback (tear down, build the RCCL loop)")
+                torch.cuda.synchronize()
+                dist.barrier()              # every rank has stopped launching into the exchange
+                del loop                    # (its exchange blocks stay allocated until the process ends -- 2 MB; nothing a peer has
+                import gc                   # mapped is freed under it)
+                gc.collect()
+                p2p = False
+                loop, workload, extra = build_ddpg(False, False)
+                extra["dp_mode"]["fell_back_from"] = "p2p"
+                extra["dp_mode"]["fell_back_why"] = why or ("another rank's exchange failed" if not ok_all else "the ranks' weights differed")
         ddpg_loop = loop
-        run = loop.run       # every step a hipGraph replay (G-step graphs where aligned, single-step graphs elsewhere)
-        workload = (f"{vname} N={n}/GPU + full DDPG learn() x{args.updates_per_step} per vector step (actor/critic 400x300, "
-                    f"batch {args.batch}, OU noise, replay ring {args.replay_slots}xN) (BASELINE config {5 if variant else 3})")
-        if loop.graph_steps:
-            launch = (f"every vector step a hipGraph replay: graphs of {loop.graph_steps}, 4 and 1 whole steps "
-                      f"serve every ring position (device cursor)" + ((" -- no collective: each rank's two Adam launches read the peers' gradient "
-                                                                "buffers themselves (IPC-opened device memory, flag barrier)" if p2p else
-                                                                " -- the two RCCL gradient all-reduces of a step are nodes of its graph")
-                                                               if loop.dp else "") if not (loop.dp and not loop.dp_single_graph) else
-                      "three hipGraph segments per step with the two RCCL gradient all-reduces between them")
-        else:
-            launch = "eager, learn() as a hipGraph" if loop.use_graph else "eager"
-        order = ("pipelined: learn() of vector step t (batch from the steps up to t-2) runs beside the policy + env launches of "
-                 "steps t-1 and t on a second chain of the graph; the policy acts with the weights learn() of step t-1 left"
-                 if loop.pipeline else "serial: policy, env step, then learn() on a window that includes the new step")
-        extra = {"batch": args.batch, "updates_per_step": args.updates_per_step,
-                 "replay_capacity": args.replay_slots * n, "launch": launch, "order": order,
-                 "dp_mode": (None if not loop.dp else
-                             {"asked": args.dp_mode, "decided_by": dp_asked, "this_rank_vote": bool(p2p_vote if p2p else dp_vote),
-                              "agreed_by_all_ranks": "p2p" if p2p else ("graph" if loop.dp_single_graph else "segments")}),
-                 "env_steps_per_update": n / args.updates_per_step, "setup_vector_steps": loop.vector_steps,
-                 "note": ("throughput of the configuration BASELINE.json names; how the same loop trains at this and at other "
-                          "update ratios (--updates-per-step): profiles/r03_training_behaviour.md")}
+        run = lambda k_steps: ddpg_loop.run(k_steps)      # every step a hipGraph replay (G-step graphs where aligned, single-step graphs elsewhere)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -645,12 +698,7 @@ def main():
         # data-parallel ranks must hold the SAME weights after every update (gradients averaged at both optimizer sites, rank-ordered
         # sums in the peer-to-peer exchange): compared here, after the timed region -- a run whose ranks drifted apart is not a
         # data-parallel run, whatever its throughput
-        flat = torch.cat([p.detach().reshape(-1) for net in ddpg_loop.agent._nets() for p in net.parameters()])
-        h = torch.stack([flat.view(torch.int32).to(torch.int64).sum(), (flat.view(torch.int32).to(torch.int64) * torch.arange(
-            1, flat.numel() + 1, device=dev, dtype=torch.int64)).sum()]).cpu()
-        hs = [torch.zeros_like(h) for _ in range(world)]
-        dist.all_gather(hs, h if dist.get_backend() != "nccl" else h.to(dev))
-        same = all(torch.equal(hs[0].cpu(), x.cpu()) for x in hs[1:]) and bool(torch.isfinite(flat).all())
+        same, hs = weights_agree(ddpg_loop, dev, world)
         out["config"]["dp_mode"]["ranks_hold_the_same_weights"] = same
         if not same:
             print(f"bench.py: rank {rank}: the ranks' weights differ after the run (checksums {[x.tolist() for x in hs]}): the gradient "

@@ -507,6 +507,26 @@ def test_p2p_exchange_probe_and_auto_mode_on_one_gpu(gpu_device):
                                                            "agreed_by_all_ranks": "p2p", "ranks_hold_the_same_weights": True}
 
 
+@pytest.mark.gpu
+def test_bench_auto_mode_falls_back_to_collectives_when_the_exchange_fails_its_validation(gpu_device):
+    """--dp-mode auto trusts the probed peer-to-peer exchange only after it has carried the REAL loop for two graph lengths of steps on
+    every rank; if one rank reports a failure there (forced here on rank 1), every rank drops the exchange, the loop is built again
+    with all-reduces in three graph segments per step, and the line says what happened -- a first run on a new node still gives a
+    number.  (TT_DIST_BACKEND=gloo: two ranks on the ONE GPU of the test box.)"""
+    import json
+    import subprocess
+    env = dict(os.environ, TT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", TT_P2P_TIMEOUT_S="30", TT_BENCH_TEST_P2P_FAIL="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n-envs", "4096", "--steps", "20", "--warmup", "5",
+                        "--repeats", "0", "--watchdog-seconds", "280"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "going on with RCCL all-reduces in three graph segments" in r.stderr
+    d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    m = d["config"]["dp_mode"]
+    assert d["n_gpus"] == 2 and m["agreed_by_all_ranks"] == "segments" and m["fell_back_from"] == "p2p", m
+    assert m["ranks_hold_the_same_weights"] is True and "three hipGraph segments" in d["config"]["launch"]
+
+
 def test_bench_refuses_fewer_gpus_than_ranks():
     """`python bench.py --gpus N` starts N ranks itself; with fewer than N GPUs visible it prints no line and exits 2."""
     import subprocess
