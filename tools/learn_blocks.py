@@ -62,6 +62,11 @@ def report(a, title, lib=None):
         print(f"  {name:24s} {g:3d} wgs  start {st.min():6.2f}..{st.max():6.2f}  end {en.min():6.2f}..{en.max():6.2f}  "
               f"median wg {np.median(en - st):5.2f}  max wg {np.max(en - st):5.2f}{gap}")
         prev_end = en.max()
+        if k in (2, 4):      # the weight-gradient launches hold three kinds of workgroups: which kind ends the launch?
+            kinds = (("dW2 tiles", 0, 133), ("dW1 tiles", 133, 158), ("column sums", 158, g))
+            print("      by kind (end relative to the launch's first start; median / max workgroup duration): " + "; ".join(
+                f"{nm} [{a}, {b}): end {en[a:b].min() - st.min():.2f}..{en[a:b].max() - st.min():.2f}, {np.median((en - st)[a:b]):.2f} / {(en - st)[a:b].max():.2f}"
+                for nm, a, b in kinds if b > a))
     print(f"  chain: first start -> last end {prev_end:6.2f} us")
     if a[5, 0, 0] and 0 < t0 - a[5, 0, 0] < 100000:
         print(f"  the previous learn()'s last workgroup ended {(t0 - a[5, 0, 0]) / 100.0:5.2f} us before this one's first began")
