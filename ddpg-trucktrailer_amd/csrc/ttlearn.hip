@@ -1344,7 +1344,9 @@ template <bool ROWSCALE, bool TAIL>
 __device__ __forceinline__ void bwd_weights_body(const int blk, const int n, const int critic, const float *__restrict__ obs,
                                                  const float *__restrict__ action, const Saved &sv, const BwdOut &d, const Grads &G,
                                                  const AdamFused &A, const RowScale &RS, float (&part)[4][4][256],
-                                                 float *__restrict__ f_s, const TailSync &ts, const long long tail_epoch) {
+                                                 float *__restrict__ f_s, const TailSync &ts, const long long tail_epoch,
+                                                 _Float16 *__restrict__ stage_s) {
+    // stage_s: 4 x 1024 halves of LDS (8 KB) of the workgroup's own: the forward-image pieces of a dW2 workgroup's patch
     auto fill_factors = [&]() __attribute__((always_inline)) {       // every thread of the workgroup calls this once
         if (ROWSCALE) {
             if (TAIL && ts.hints) {
@@ -1404,8 +1406,12 @@ __device__ __forceinline__ void bwd_weights_body(const int blk, const int n, con
         const int jt = blk / NG, grp = blk - jt * NG;
         const int j = jt * 16 + l15, c0 = grp * 64 + 4 * l15;
         const bool jok = j < H2, cok = c0 < H1;
-        const int col = grp * 64 + 4 * l15 + wave;                       // wave w finishes output tile t = w: columns c0 + t
-        const bool own = col < H1 && grp * 64 + 4 * l15 < H1;
+        // Who finishes which of the block's 16 x 64 outputs: wave w rows 4w .. 4w+3, lane = column (round 4).  The optimizer state
+        // and the updated weights then move as whole 256-byte rows per instruction (with "wave = column mod 4" every instruction
+        // touched four rows at a quarter of each line), and the eight columns of a 16-byte image piece sit in eight lanes of ONE
+        // wave: the patch needs no workgroup barrier.
+        const int col = grp * 64 + lane;
+        const bool own = col < H1;
         f32x4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1439,7 +1445,7 @@ __device__ __forceinline__ void bwd_weights_body(const int blk, const int n, con
         if (A.on && own) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int jr = jt * 16 + l4 * 4 + r;
+                const int jr = jt * 16 + wave * 4 + r;
                 if (jr < H2) el[r] = adam_load(A, 4, (size_t)jr * H1 + col);
             }
         }
@@ -1488,16 +1494,18 @@ __device__ __forceinline__ void bwd_weights_body(const int blk, const int n, con
         WST(3);
         lds_barrier();
         WST(4);
-        // wave w finishes output tile t = w: sum the four K-quarters in a fixed order
-        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(&part[0][wave][lane * 4]);
-        const f32x4 p1 = *reinterpret_cast<const f32x4 *>(&part[1][wave][lane * 4]);
-        const f32x4 p2 = *reinterpret_cast<const f32x4 *>(&part[2][wave][lane * 4]);
-        const f32x4 p3 = *reinterpret_cast<const f32x4 *>(&part[3][wave][lane * 4]);
+        // element (row 4 wave + r, column lane) of the block: tile t = lane & 3 of the MFMA layout, held there by lane
+        // wave * 16 + (lane >> 2), register r; the four K-quarters summed in a fixed order
+        const int src = (wave * 16 + (lane >> 2)) * 4, tq = lane & 3;
+        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(&part[0][tq][src]);
+        const f32x4 p1 = *reinterpret_cast<const f32x4 *>(&part[1][tq][src]);
+        const f32x4 p2 = *reinterpret_cast<const f32x4 *>(&part[2][tq][src]);
+        const f32x4 p3 = *reinterpret_cast<const f32x4 *>(&part[3][tq][src]);
         float pnew[4] = {0.f, 0.f, 0.f, 0.f}, tnew[4] = {0.f, 0.f, 0.f, 0.f};      // updated parameter / target (0 = padding)
         if (own) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int jr = jt * 16 + l4 * 4 + r;
+                const int jr = jt * 16 + wave * 4 + r;
                 if (jr < H2) {
                     const float g = ((p0[r] + p1[r]) + p2[r]) + p3[r];
                     st_out(&G.w2[(size_t)jr * H1 + col], g);
@@ -1510,35 +1518,39 @@ __device__ __forceinline__ void bwd_weights_body(const int blk, const int n, con
         }
         WST(5);
         if (A.on && (A.img_p || A.img_t)) {
-            // The block's 16 x 64 patch of fc2 in the images the learn() kernels read instead of w2 (fragment order, see
-            // IMG_FWD above): exactly two consecutive 1 KB fragments of each forward plane (rows = tile jt, k32 steps
-            // 2 grp, 2 grp + 1) and half a fragment (512 B) of each of the group's four backward tiles.  Pieces are staged
-            // in LDS in that order and leave as 16-byte stores; scattered 2-byte stores cost 10 us per launch.
-            _Float16 (*stage)[1024] = reinterpret_cast<_Float16 (*)[1024]>(&part[0][0][0]);      // 6 x 2 KB of the 16 KB
-            lds_barrier();                                              // every wave has read its partial sums
-            const int kq = 4 * l15 + wave;                                // column inside the group
+            // The block's 16 x 64 patch of fc2 in the images the learn() kernels read instead of w2 (fragment order, see IMG_FWD
+            // above): two consecutive 1 KB fragments of each forward plane (rows = tile jt, k32 steps 2 grp, 2 grp + 1) -- a
+            // 16-byte piece is one row's eight consecutive columns: eight lanes of this wave, put together in the wave's share of
+            // stage_s (LDS operations of one wave complete in order: no barrier) -- and half a fragment of each of the group's four
+            // backward tiles, where a lane's four rows ARE four consecutive halves: 8-byte stores straight from registers.
+            const int kq = lane;                                          // column inside the group
+            uint32_t bh[2] = {0u, 0u}, bm[2] = {0u, 0u};                  // this lane's four rows of the backward planes (h, m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int lr = l4 * 4 + r;                                // row inside the tile
+                const int lr = wave * 4 + r;                              // row inside the tile
                 const float sp = pnew[r] * SWL, st = tnew[r] * SWL;
                 const _Float16 ph = (_Float16)sp, pm = (_Float16)(sp - (float)ph), th = (_Float16)st, tm = (_Float16)(st - (float)th);
                 const int f = (kq >> 5) * 512 + (((kq >> 3) & 3) * 16 + lr) * 8 + (kq & 7);
-                const int b = wave * 256 + ((l4 >> 1) * 16 + l15) * 8 + (l4 & 1) * 4 + r;
-                stage[0][f] = ph; stage[1][f] = pm; stage[2][b] = ph; stage[3][b] = pm; stage[4][f] = th; stage[5][f] = tm;
+                stage_s[f] = ph; stage_s[1024 + f] = pm; stage_s[2048 + f] = th; stage_s[3072 + f] = tm;
+                bh[r >> 1] |= (uint32_t)__builtin_bit_cast(unsigned short, ph) << (16 * (r & 1));
+                bm[r >> 1] |= (uint32_t)__builtin_bit_cast(unsigned short, pm) << (16 * (r & 1));
             }
-            lds_barrier();
+            if (A.img_p) {
+                // backward planes: piece (kq & 3) * 32 + (wave >> 1) * 16 + (kq >> 2) of the staging order, halves (wave & 1) * 4 .. + 3
+                const size_t o = 2 * IMG_FWD + ((size_t)((grp * 4 + (kq & 3)) * BW_STEPS + (jt >> 1)) * 64 + (jt & 1) * 32 + (wave >> 1) * 16 + (kq >> 2)) * 8 +
+                                 (wave & 1) * 4;
+                *reinterpret_cast<uint2 *>(A.img_p + o) = make_uint2(bh[0], bh[1]);
+                *reinterpret_cast<uint2 *>(A.img_p + o + IMG_T) = make_uint2(bm[0], bm[1]);
+            }
+            __builtin_amdgcn_wave_barrier();
             const size_t fbase = (size_t)(jt * FW_STEPS + 2 * grp) * 512;
             const int fcount = grp < NG - 1 ? 128 : 64;                   // the last group has one k32 step (columns 384..415)
-            for (int q = tid; q < 6 * 128; q += 256) {
-                const int arr = q >> 7, w = q & 127;
-                const uint4 v = *reinterpret_cast<const uint4 *>(&stage[arr][w * 8]);
-                if (arr == 2 || arr == 3) {
-                    if (A.img_p) {
-                        const size_t o = 2 * IMG_FWD + (arr == 3 ? IMG_T : 0) +
-                                         ((size_t)((grp * 4 + (w >> 5)) * BW_STEPS + (jt >> 1)) * 64 + (jt & 1) * 32) * 8 + (w & 31) * 8;
-                        st_out16(A.img_p + o, v);
-                    }
-                } else if (w < fcount) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                // this wave's 128 pieces: array (p.h, p.m, t.h, t.m) x k32 half x k8 group x its four rows
+                const int pc = lane + 64 * i, arr = pc >> 5, w = ((pc >> 4) & 1) * 64 + ((pc >> 2) & 3) * 16 + wave * 4 + (pc & 3);
+                const uint4 v = *reinterpret_cast<const uint4 *>(&stage_s[arr * 1024 + w * 8]);
+                if (w < fcount) {
                     _Float16 *img = arr < 2 ? A.img_p : (A.tgt[4] ? A.img_t : nullptr);
                     if (img) st_out16(img + ((arr & 1) ? IMG_FWD : 0) + fbase + w * 8, v);
                 }
@@ -1723,8 +1735,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
                                                      const BwdOut d, const Grads G, const AdamFused A, const RowScale RS) {
     __shared__ __attribute__((aligned(16))) float part[4][4][256];     // [wave][tile][lane*4 + r]
     __shared__ float f_s[ROWSCALE ? MAXB : 1];                         // the rows' factors, computed once per workgroup
+    __shared__ __attribute__((aligned(16))) _Float16 stage_s[4 * 1024];   // forward-image pieces of a dW2 workgroup's patch
     kernarg_warm<24 + (int)sizeof(Saved) + (int)sizeof(BwdOut) + (int)sizeof(Grads) + (int)sizeof(AdamFused) + (int)sizeof(RowScale)>();
-    bwd_weights_body<ROWSCALE, false>(blockIdx.x, n, critic, obs, action, sv, d, G, A, RS, part, f_s, TailSync{nullptr, nullptr, 0, nullptr}, 0);
+    bwd_weights_body<ROWSCALE, false>(blockIdx.x, n, critic, obs, action, sv, d, G, A, RS, part, f_s, TailSync{nullptr, nullptr, 0, nullptr}, 0,
+                                      stage_s);
 }
 
 // learn()'s last two launches in ONE grid (the single-rank chain where the policy launch is small or learn() repeats per step):
@@ -1753,10 +1767,11 @@ __global__ __launch_bounds__(64 * NW) void k_actor_tail(const int n, const float
         return;
     }
     if (threadIdx.x >= 256) return;
-    static_assert(sizeof(float) * (H1S_FLOATS + TR * DS + H1 * IN) >= sizeof(float) * (4 * 4 * 256 + MAXB), "the weight kernel's LDS fits");
+    static_assert(sizeof(float) * (H1S_FLOATS + TR * DS + H1 * IN) >= sizeof(float) * (4 * 4 * 256 + MAXB + 2048), "the weight kernel's LDS fits");
     float (&part)[4][4][256] = *reinterpret_cast<float (*)[4][4][256]>(lds);
     const long long epoch = *A.step_dev;
-    bwd_weights_body<true, true>((int)blockIdx.x - nb, n, 0, obs, nullptr, sv, d, G, A, RS, part, lds + 4 * 4 * 256, ts, epoch);
+    bwd_weights_body<true, true>((int)blockIdx.x - nb, n, 0, obs, nullptr, sv, d, G, A, RS, part, lds + 4 * 4 * 256, ts, epoch,
+                                 reinterpret_cast<_Float16 *>(lds + 4 * 4 * 256 + MAXB));
 }
 
 // ------------------------------------------------------------------------------------------------------
