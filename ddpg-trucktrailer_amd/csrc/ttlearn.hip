@@ -521,15 +521,9 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
                 }
         };
         static_assert(GU == GU_F, "the prefetched group is group 0");
-#pragma unroll
-        for (int u = 0; u < GU; ++u)
-#pragma unroll
-            for (int i = 0; i < MT2; ++i) { bcur[u][i][0] = bpre[u][i][0]; bcur[u][i][1] = bpre[u][i][1]; }
-#pragma unroll
-        for (int g = 0; g < NGRP; ++g) {
-            if (g + 1 < NGRP) load_group(g + 1, bnxt);
-            else load_l2_vectors();
-            __builtin_amdgcn_sched_barrier(0);
+        // Two fragment sets that swap roles from group to group (the loop is unrolled: no copies).  Handing the next set over with
+        // `bcur = bnxt` cost ~460 register moves per wave in this phase -- as many issue cycles as its MFMAs.
+        auto products = [&](const int g, const f16x8 (&b)[GU][MT2][2]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 const int c = g * GU + u;
@@ -537,18 +531,27 @@ __device__ __forceinline__ void fwd_small_body(const int n, const float *__restr
                     const f16x8 a_h = *reinterpret_cast<const f16x8 *>(ah + 32 * c);
                     const f16x8 a_m = *reinterpret_cast<const f16x8 *>(ah + TR * HSH + 32 * c);
 #pragma unroll
-                    for (int i = 0; i < MT2; ++i) if (i < nt) acc2[i] = mfma_h(a_m, bcur[u][i][0], acc2[i]);
+                    for (int i = 0; i < MT2; ++i) if (i < nt) acc2[i] = mfma_h(a_m, b[u][i][0], acc2[i]);
 #pragma unroll
-                    for (int i = 0; i < MT2; ++i) if (i < nt) acc2[i] = mfma_h(a_h, bcur[u][i][1], acc2[i]);
+                    for (int i = 0; i < MT2; ++i) if (i < nt) acc2[i] = mfma_h(a_h, b[u][i][1], acc2[i]);
 #pragma unroll
-                    for (int i = 0; i < MT2; ++i) if (i < nt) acc2[i] = mfma_h(a_h, bcur[u][i][0], acc2[i]);
+                    for (int i = 0; i < MT2; ++i) if (i < nt) acc2[i] = mfma_h(a_h, b[u][i][0], acc2[i]);
                 }
             }
+        };
+        auto step = [&](const int g, const f16x8 (&use)[GU][MT2][2], f16x8 (&fill)[GU][MT2][2]) __attribute__((always_inline)) {
+            if (g + 1 < NGRP) load_group(g + 1, fill);
+            else load_l2_vectors();
             __builtin_amdgcn_sched_barrier(0);
+            products(g, use);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        (void)bcur;
 #pragma unroll
-            for (int u = 0; u < GU; ++u)
-#pragma unroll
-                for (int i = 0; i < MT2; ++i) { bcur[u][i][0] = bnxt[u][i][0]; bcur[u][i][1] = bnxt[u][i][1]; }
+        for (int g = 0; g < NGRP; g += 2) {
+            if (g == 0) step(0, bpre, bnxt);
+            else step(g, bcur, bnxt);
+            if (g + 1 < NGRP) step(g + 1, bnxt, bcur);
         }
 #pragma unroll
         for (int i = 0; i < MT2; ++i) acc2[i] *= UNSC_L;
@@ -1028,31 +1031,33 @@ __device__ __forceinline__ void bwd_rows_body(const int n, const int mode, const
                 }
         };
         static_assert(GU == GU_B, "the prefetched group is group 0");
-#pragma unroll
-        for (int u = 0; u < GU; ++u)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { bcur[u][t][0] = bpre[u][t][0]; bcur[u][t][1] = bpre[u][t][1]; }
-#pragma unroll
-        for (int g = 0; g < NGRP; ++g) {
-            if (g + 1 < NGRP) load_group(g + 1, bnxt);
-            __builtin_amdgcn_sched_barrier(0);
+        // two fragment sets that swap roles (no copies: see the forward's layer 2)
+        auto products = [&](const int g, const f16x8 (&b)[GU][4][2]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 const int c = g * GU + u;
                 const f16x8 a_h = *reinterpret_cast<const f16x8 *>(ah + 32 * c);
                 const f16x8 a_m = *reinterpret_cast<const f16x8 *>(ah + TR * DSH + 32 * c);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = mfma_h(a_m, bcur[u][t][0], acc[t]);
+                for (int t = 0; t < 4; ++t) acc[t] = mfma_h(a_m, b[u][t][0], acc[t]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = mfma_h(a_h, bcur[u][t][1], acc[t]);
+                for (int t = 0; t < 4; ++t) acc[t] = mfma_h(a_h, b[u][t][1], acc[t]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = mfma_h(a_h, bcur[u][t][0], acc[t]);
+                for (int t = 0; t < 4; ++t) acc[t] = mfma_h(a_h, b[u][t][0], acc[t]);
             }
+        };
+        auto step = [&](const int g, const f16x8 (&use)[GU][4][2], f16x8 (&fill)[GU][4][2]) __attribute__((always_inline)) {
+            if (g + 1 < NGRP) load_group(g + 1, fill);
             __builtin_amdgcn_sched_barrier(0);
+            products(g, use);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        (void)bcur;
 #pragma unroll
-            for (int u = 0; u < GU; ++u)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { bcur[u][t][0] = bnxt[u][t][0]; bcur[u][t][1] = bnxt[u][t][1]; }
+        for (int g = 0; g < NGRP; g += 2) {
+            if (g == 0) step(0, bpre, bnxt);
+            else step(g, bcur, bnxt);
+            if (g + 1 < NGRP) step(g + 1, bnxt, bcur);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
